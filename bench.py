@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""Benchmark of the EEG -> LSTM distillation training step (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one batch of synthetic input already resident in
+HBM: fused band-pass + z-score -> 2-layer LSTM (hidden 768) forward -> fc -> cosine
+distillation loss -> backward -> gradient all-reduce (RCCL, N>1) -> RMSprop step.
+Workload = BASELINE.json configs[1]: per-GPU batch 256, 128 ch x 500 samples, DINOv2 dim 384,
+bf16 MFMA operands with f32 accumulate/state.  Weak scaling: per-GPU work is fixed.
+Rank 0 prints ONE JSON line (metric, roofline of the dominant kernel, CPU baseline).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16, MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
+HBM_PEAK_GBS = 8000.0            # HBM3E spec, same guide
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (cfg2: 256)")
+    ap.add_argument("--channels", type=int, default=128)
+    ap.add_argument("--samples", type=int, default=500)
+    ap.add_argument("--hidden", type=int, default=768)
+    ap.add_argument("--layers", type=int, default=2)
+    ap.add_argument("--dim", type=int, default=384)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--pool", type=int, default=4, help="resident synthetic batches per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    return ap.parse_args()
+
+
+def synthetic_pool(n, C, T, D, rank, device):
+    """x = N(0,1) + 0.5 sin(2 pi 40 t / 1000) (utils/GenerateRandomEEGNoise.py:4-19), seeds 43/44/45."""
+    g = torch.Generator(device="cpu").manual_seed(43 + 1000 * rank)
+    t = torch.arange(T, dtype=torch.float32) / 1000.0
+    x = torch.randn(n, C, T, generator=g) + 0.5 * torch.sin(2 * np.pi * 40 * t)
+    tg = torch.randn(n, D, generator=torch.Generator().manual_seed(44 + 1000 * rank))
+    lab = torch.randint(0, 40, (n,), generator=torch.Generator().manual_seed(45 + 1000 * rank))
+    return x.to(device), tg.to(device), lab.to(device)
+
+
+def time_cell_kernels(args, device, dtype):
+    """Average launch duration of the per-timestep cell kernels, HIP events on the launch stream."""
+    from cerebralsignalnetworks_amd import cabi
+    B, H = args.batch, args.hidden
+    w = (torch.randn(4 * H, H, device=device) / np.sqrt(H)).to(dtype)
+    wt = w.t().contiguous()
+    h = torch.randn(B, H, device=device).to(dtype)
+    c = torch.randn(B, H, device=device)
+    xp = torch.randn(B, 4 * H, device=device)
+    dg = (torch.randn(B, 4 * H, device=device) * 0.1).to(dtype)
+    gates = torch.rand(B, 4 * H, device=device).to(dtype)
+    dcar = torch.zeros(B, H, device=device)
+    out = {}
+    n = 200
+    for name, fn in (("fwd", lambda: cabi.lstm_cell_forward(h, w, xp, c)),
+                     ("bwd", lambda: cabi.lstm_cell_backward(dg, wt, None, gates, c, c, dcar))):
+        for _ in range(10):
+            fn()
+        st = torch.cuda.current_stream()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(st)
+        for _ in range(n):
+            fn()
+        e1.record(st)
+        e1.synchronize()
+        out[name] = e0.elapsed_time(e1) * 1e-3 / n
+    return out
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+    device = torch.device("cuda", local)
+    torch.cuda.set_device(device)
+
+    from cerebralsignalnetworks_amd import Model, EEGFilters
+    from cerebralsignalnetworks_amd.trainer import DistillTrainer
+
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    B, C, T, H, L, D = args.batch, args.channels, args.samples, args.hidden, args.layers, args.dim
+    torch.manual_seed(43)
+    model = Model(input_size=C, lstm_size=H, lstm_layers=L, output_size=D, include_top=False,
+                  compute_dtype=dtype).to(device)
+    filt = EEGFilters(1000, order=3)
+    trainer = DistillTrainer(model, filt.sos, loss="cosine", lr=1e-3, optimizer="rmsprop")
+    x, tg, lab = synthetic_pool(B * args.pool, C, T, D, rank, device)
+
+    def step(i):
+        j = (i % args.pool) * B
+        return trainer.train_step(x[j:j + B], tg[j:j + B], lab[j:j + B])
+
+    for i in range(args.warmup):
+        step(i)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    loss = None
+    for i in range(args.steps):
+        loss = step(args.warmup + i)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    final_loss = float(loss.item())
+
+    if rank == 0:
+        seg_per_s = world * B * args.steps / elapsed
+        flops_per_seg = 3.0 * 2.0 * T * sum(4 * H * ((C if l == 0 else H) + H) for l in range(L))
+        res = {
+            "metric": "EEG-segments/sec training (128ch x 500, hidden=768)",
+            "value": seg_per_s, "unit": "segments/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "cfg2: fused EEG band-pass+z-score -> 2-layer LSTM fwd/bwd -> cosine distill "
+                                   "-> RMSprop, precomputed random DINOv2-dim targets",
+                       "per_gpu_batch": B, "global_batch": B * world, "channels": C, "samples": T, "hidden": H,
+                       "layers": L, "embed_dim": D, "parallelism": f"dp{world}"},
+            "final_loss": final_loss,
+            "model_tflops": seg_per_s * flops_per_seg / 1e12,
+        }
+        if not args.no_kernel_timing:
+            kt = time_cell_kernels(args, device, dtype)
+            # dominant kernel: the backward cell step (K = 4H per launch); algorithmic flops per launch
+            fl_fwd = 2.0 * B * 4 * H * H
+            fl_bwd = 2.0 * B * 4 * H * H
+            dom = "bwd" if kt["bwd"] >= kt["fwd"] else "fwd"
+            ach = (fl_bwd if dom == "bwd" else fl_fwd) / kt[dom] / 1e12
+            res["roofline"] = {"bound": "mfma", "kernel": f"lstm_cell_{dom}_kernel", "achieved": ach,
+                               "peak": MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else 157.3,
+                               "unit": "TFLOP/s",
+                               "frac": ach / (MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else 157.3),
+                               "traffic": None,
+                               "us_per_launch": {k: v * 1e6 for k, v in kt.items()},
+                               "flops_per_launch": fl_bwd if dom == "bwd" else fl_fwd}
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import cpu_path, eeg_filter
+            nb = 8
+            xs = eeg_filter.synthetic_eeg(nb, C, T, seed=43)
+            ts = np.random.default_rng(44).standard_normal((nb, D)).astype(np.float32)
+            cb = cpu_path.time_cpu_train_steps(xs, ts, filt.sos, hidden=H, layers=L, steps=2, warmup=1)
+            res["cpu_baseline"] = {"value": cb["seg_per_s"], "unit": "segments/s", "cores": cb["cores"],
+                                   "kind": "port",
+                                   "sample": f"batch {nb}, 1 warm-up + 2 timed steps of scipy sosfilt + z-score -> "
+                                             f"torch.nn.LSTM({C}->{H}x{L}) fp32 -> Linear -> cosine -> backward -> RMSprop"}
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

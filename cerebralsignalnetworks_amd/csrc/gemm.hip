@@ -1,0 +1,424 @@
+// GEMMs of the LSTM path (input projections, input gradients, weight gradients).
+// They replace the GEMM calls inside ATen's LSTM that nn.LSTM reaches at
+// /root/reference/LSTMDistill.py:118,132.
+//
+//  gemm_generic<T>   any strides, T in {f32, bf16}; operands are widened to f32 and multiplied
+//                    with the exact-f32 MFMA v_mfma_f32_16x16x4_f32 (bitwise an fmaf chain).
+//                    This is the CSN_F32 parity path and the fallback for odd shapes.
+//  gemm_nt_bf16      C[M,N] = A[M,K] * Bt[N,K]^T, 128x128x64 tiles, 4 waves (2x2) of 64x64,
+//                    v_mfma_f32_16x16x32_bf16, double-buffered LDS with an XOR swizzle that makes
+//                    the ds_read_b128 fragment reads conflict-free, register-staged prefetch.
+//                    MFMA-bound roofline; algorithmic flops 2*M*N*K.
+//  gemm_tn_bf16      C[M,N] = A[K,M]^T * B[K,N] (weight gradient: contraction over T*B rows),
+//                    operands staged row-major [k][m] / [k][n] in LDS and read column-major with
+//                    ds_read_b64_tr_b16; split-K over blockIdx.z into float32 slabs that a
+//                    fixed-order reduction combines (bitwise reproducible, no atomics).
+#include "csn_common.h"
+
+namespace csn {
+
+// =====================================================================================
+// generic strided GEMM on the f32 MFMA
+// =====================================================================================
+template <typename T>
+__global__ void __launch_bounds__(256)
+gemm_generic_kernel(const T* __restrict__ A, int64_t sam, int64_t sak, const T* __restrict__ Bm, int64_t sbk,
+                    int64_t sbn, const float* __restrict__ bias, void* __restrict__ Cv, int64_t ldc, int64_t M,
+                    int64_t N, int64_t K, int out_bf16, int accumulate, int64_t k_per_split, int64_t slab_stride) {
+  __shared__ float As[16][64 + 1];
+  __shared__ float Bs[16][64 + 1];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int64_t m0 = (int64_t)blockIdx.y * 64, n0 = (int64_t)blockIdx.x * 64;
+  const int64_t kbeg = (int64_t)blockIdx.z * k_per_split;
+  const int64_t kend = (kbeg + k_per_split < K) ? kbeg + k_per_split : K;
+  const bool a_kfast = (sak == 1), b_kfast = (sbk == 1);
+
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  for (int64_t k0 = kbeg; k0 < kend; k0 += 16) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = tid + i * 256;
+      int kk, mm;
+      if (a_kfast) { kk = idx & 15; mm = idx >> 4; } else { mm = idx & 63; kk = idx >> 6; }
+      const int64_t m = m0 + mm, k = k0 + kk;
+      As[kk][mm] = (m < M && k < kend) ? to_f32(A[m * sam + k * sak]) : 0.0f;
+      int kb, nn;
+      if (b_kfast) { kb = idx & 15; nn = idx >> 4; } else { nn = idx & 63; kb = idx >> 6; }
+      const int64_t n = n0 + nn, k2 = k0 + kb;
+      Bs[kb][nn] = (n < N && k2 < kend) ? to_f32(Bm[k2 * sbk + n * sbn]) : 0.0f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      float av[2], bv[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) av[i] = As[kk * 4 + (lane >> 4)][wm * 32 + i * 16 + (lane & 15)];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) bv[j] = Bs[kk * 4 + (lane >> 4)][wn * 32 + j * 16 + (lane & 15)];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          // operands swapped: D[row = n][col = m]  -> lane holds m = lane&15, n = (lane>>4)*4 + r
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[j], av[i], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  float* Cf = (float*)Cv + (int64_t)blockIdx.z * slab_stride;
+  bf16_t* Cb = (bf16_t*)Cv;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int64_t m = m0 + wm * 32 + i * 16 + (lane & 15);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t n = n0 + wn * 32 + j * 16 + (lane >> 4) * 4 + r;
+        if (m < M && n < N) {
+          float v = acc[i][j][r];
+          if (bias) v += bias[n];
+          if (out_bf16) Cb[m * ldc + n] = (bf16_t)v;
+          else if (accumulate) Cf[m * ldc + n] += v;
+          else Cf[m * ldc + n] = v;
+        }
+      }
+    }
+}
+
+static int launch_generic(const void* A, int64_t sam, int64_t sak, const void* Bm, int64_t sbk, int64_t sbn,
+                          const float* bias, void* C, int64_t ldc, int64_t M, int64_t N, int64_t K, int dtype,
+                          int out_dtype, int accumulate, int splits, int64_t slab_stride, hipStream_t st) {
+  dim3 grid((unsigned)((N + 63) / 64), (unsigned)((M + 63) / 64), (unsigned)splits);
+  int64_t kper = (K + splits - 1) / splits;
+  kper = (kper + 15) / 16 * 16;
+  if (dtype == CSN_BF16)
+    gemm_generic_kernel<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)A, sam, sak, (const bf16_t*)Bm, sbk, sbn, bias, C,
+                                                      ldc, M, N, K, out_dtype == CSN_BF16, accumulate, kper,
+                                                      slab_stride);
+  else
+    gemm_generic_kernel<float><<<grid, 256, 0, st>>>((const float*)A, sam, sak, (const float*)Bm, sbk, sbn, bias, C,
+                                                     ldc, M, N, K, out_dtype == CSN_BF16, accumulate, kper,
+                                                     slab_stride);
+  CSN_LAUNCH_CHECK();
+  return CSN_OK;
+}
+
+// =====================================================================================
+// bf16 NT GEMM, 128x128x64 tiles
+// =====================================================================================
+// LDS image of one operand tile: 128 rows x 64 k (bf16) = 128-byte rows, eight 16-byte chunks
+// per row.  Chunk ch of row r is stored at chunk (ch ^ ((r >> 1) & 7)): with that XOR the 16
+// lanes of every ds_read_b128 lane group ({0-3,12-15,20-27}, ...) hit 16 distinct 16-byte
+// slots of the 256-byte bank row when lane l reads row (l & 15), chunk kk*4 + (l >> 4).
+__device__ __forceinline__ int nt_lds_off(int row, int chunk) {  // byte offset inside a tile
+  return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
+}
+
+template <typename OutT>
+__global__ void __launch_bounds__(256)
+gemm_nt_bf16_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ Bt, const float* __restrict__ bias,
+                    OutT* __restrict__ C, int64_t M, int64_t N, int64_t K, int accumulate) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 buffers x (A 16 KB + B 16 KB)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int64_t m0 = (int64_t)blockIdx.y * 128, n0 = (int64_t)blockIdx.x * 128;
+  const int nk = (int)((K + 63) / 64);
+
+  // global->register staging: each thread moves 4 chunks of A and 4 of B per k-tile.
+  // chunk id q = tid + i*256 (0..1023): row = q >> 3, chunk = q & 7 (8 lanes cover one 128-B row).
+  uint4 ra[4], rb[4];
+  auto load_tile = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int q = tid + i * 256;
+      const int row = q >> 3, ch = q & 7;
+      const int64_t k = (int64_t)kt * 64 + ch * 8;
+      const int64_t am = m0 + row, bn = n0 + row;
+      ra[i] = (am < M && k < K) ? *reinterpret_cast<const uint4*>(A + am * K + k) : make_uint4(0, 0, 0, 0);
+      rb[i] = (bn < N && k < K) ? *reinterpret_cast<const uint4*>(Bt + bn * K + k) : make_uint4(0, 0, 0, 0);
+    }
+  };
+  auto store_tile = [&](int buf) {
+    char* a_s = smem + buf * 32768;
+    char* b_s = a_s + 16384;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int q = tid + i * 256;
+      const int row = q >> 3, ch = q & 7;
+      *reinterpret_cast<uint4*>(a_s + nt_lds_off(row, ch)) = ra[i];
+      *reinterpret_cast<uint4*>(b_s + nt_lds_off(row, ch)) = rb[i];
+    }
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) load_tile(kt + 1);
+    const char* a_s = smem + buf * 32768;
+    const char* b_s = a_s + 16384;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8 af[4], bfr[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        af[i] = *reinterpret_cast<const bf16x8*>(a_s + nt_lds_off(wm * 64 + i * 16 + (lane & 15), kk * 4 + (lane >> 4)));
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        bfr[j] = *reinterpret_cast<const bf16x8*>(b_s + nt_lds_off(wn * 64 + j * 16 + (lane & 15), kk * 4 + (lane >> 4)));
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          // swapped operands: D[row = n][col = m]: lane holds m = lane&15, n = (lane>>4)*4 + r
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nk) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int64_t m = m0 + wm * 64 + i * 16 + (lane & 15);
+    if (m >= M) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t n = n0 + wn * 64 + j * 16 + (lane >> 4) * 4;
+      if (n + 3 < N) {
+        f32x4 v = acc[i][j];
+        if (bias) {
+          const float4 bz = *reinterpret_cast<const float4*>(bias + n);
+          v[0] += bz.x; v[1] += bz.y; v[2] += bz.z; v[3] += bz.w;
+        }
+        if constexpr (sizeof(OutT) == 4) {
+          float4* dst = reinterpret_cast<float4*>((float*)C + m * N + n);
+          if (accumulate) { const float4 o = *dst; v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w; }
+          *dst = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+          bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+          *reinterpret_cast<bf16x4*>((bf16_t*)C + m * N + n) = o;
+        }
+      } else {
+        for (int r = 0; r < 4; ++r)
+          if (n + r < N) {
+            float v = acc[i][j][r] + (bias ? bias[n + r] : 0.f);
+            if constexpr (sizeof(OutT) == 4) {
+              float* dst = (float*)C + m * N + n + r;
+              *dst = accumulate ? *dst + v : v;
+            } else {
+              ((bf16_t*)C)[m * N + n + r] = (bf16_t)v;
+            }
+          }
+      }
+    }
+  }
+}
+
+// =====================================================================================
+// bf16 TN GEMM (weight gradient), 128x128 output tile, BK = 32 rows of the contraction
+// =====================================================================================
+// LDS image of one operand tile: 32 k-rows x 128 columns (bf16) = 256-byte rows, eight
+// 16-column blocks per row.  Block cb of k-row r is stored at block (cb ^ s(r)),
+// s(r) = (r & 3) | (((r >> 3) & 1) << 2), so the 8 k-rows that the lower (or upper) 32 lanes of
+// a ds_read_b64_tr_b16 address fall into 8 distinct 32-byte bank windows.
+__device__ __forceinline__ int tn_lds_off(int krow, int col) {  // byte offset; col in elements
+  const int s = (krow & 3) | (((krow >> 3) & 1) << 2);
+  return krow * 256 + ((((col >> 4) ^ s) << 4) + (col & 15)) * 2;
+}
+
+// Fragment of a 16(m) x 32(k) operand from the [k][m] LDS image: lane l (g = l>>4, i = l&15)
+// ends with elements j = 0..7 = tile[k = 8g + j][m = mbase + i].
+// ds_read_b64_tr_b16 (per 16-lane group): lane 4q+p supplies the address of k-row q, columns
+// 4p..4p+3 of a 4x16 block; lane i receives column i, k-row q in element q.
+template <bool USE_TR>
+__device__ __forceinline__ bf16x8 tn_load_frag(const char* tile, int mbase, int lane) {
+  const int g = lane >> 4, i = lane & 15;
+  bf16x8 out;
+  if constexpr (USE_TR) {
+    const int q = i >> 2, p = i & 3;
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (__attribute__((address_space(3))) s16x4*)(tile + tn_lds_off(8 * g + q, mbase + 4 * p)));
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (__attribute__((address_space(3))) s16x4*)(tile + tn_lds_off(8 * g + 4 + q, mbase + 4 * p)));
+    union { s16x4 s[2]; bf16x8 b; } u;
+    u.s[0] = lo;
+    u.s[1] = hi;
+    out = u.b;
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) out[j] = *reinterpret_cast<const bf16_t*>(tile + tn_lds_off(8 * g + j, mbase + i));
+  }
+  return out;
+}
+
+template <bool USE_TR>
+__global__ void __launch_bounds__(256)
+gemm_tn_bf16_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ Bm, float* __restrict__ slabs,
+                    int64_t M, int64_t N, int64_t K, int64_t k_per_split) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * 16384];  // 2 buffers x (A 8 KB + B 8 KB)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int64_t m0 = (int64_t)blockIdx.y * 128, n0 = (int64_t)blockIdx.x * 128;
+  const int64_t kbeg = (int64_t)blockIdx.z * k_per_split;
+  const int64_t kend = (kbeg + k_per_split < K) ? kbeg + k_per_split : K;
+  const int nk = (int)((kend - kbeg + 31) / 32);
+
+  // staging: tile = 32 k-rows x 16 chunks (16 B = 8 columns); q = tid + i*256, i<2: krow = q>>4, ch = q&15
+  uint4 ra[2], rb[2];
+  auto load_tile = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int q = tid + i * 256;
+      const int kr = q >> 4, ch = q & 15;
+      const int64_t k = kbeg + (int64_t)kt * 32 + kr;
+      const int64_t am = m0 + ch * 8, bn = n0 + ch * 8;
+      ra[i] = (k < kend && am < M) ? *reinterpret_cast<const uint4*>(A + k * M + am) : make_uint4(0, 0, 0, 0);
+      rb[i] = (k < kend && bn < N) ? *reinterpret_cast<const uint4*>(Bm + k * N + bn) : make_uint4(0, 0, 0, 0);
+    }
+  };
+  auto store_tile = [&](int buf) {
+    char* a_s = smem + buf * 16384;
+    char* b_s = a_s + 8192;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int q = tid + i * 256;
+      const int kr = q >> 4, ch = q & 15;
+      *reinterpret_cast<uint4*>(a_s + tn_lds_off(kr, ch * 8)) = ra[i];
+      *reinterpret_cast<uint4*>(b_s + tn_lds_off(kr, ch * 8)) = rb[i];
+    }
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  if (nk > 0) {
+    load_tile(0);
+    store_tile(0);
+  }
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) load_tile(kt + 1);
+    const char* a_s = smem + buf * 16384;
+    const char* b_s = a_s + 8192;
+    bf16x8 af[4], bfr[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) af[i] = tn_load_frag<USE_TR>(a_s, wm * 64 + i * 16, lane);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bfr[j] = tn_load_frag<USE_TR>(b_s, wn * 64 + j * 16, lane);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+    if (kt + 1 < nk) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  float* C = slabs + (int64_t)blockIdx.z * M * N;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int64_t m = m0 + wm * 64 + i * 16 + (lane & 15);
+    if (m >= M) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t n = n0 + wn * 64 + j * 16 + (lane >> 4) * 4;
+      if (n + 3 < N && (N & 3) == 0) {
+        *reinterpret_cast<float4*>(C + m * N + n) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+      } else {
+        for (int r = 0; r < 4; ++r)
+          if (n + r < N) C[m * N + n + r] = acc[i][j][r];
+      }
+    }
+  }
+}
+
+static int tn_splits(int64_t M, int64_t N, int64_t K) {
+  const int64_t tiles = ((M + 127) / 128) * ((N + 127) / 128);
+  int64_t s = (1024 + tiles - 1) / tiles;          // aim at >= 4 workgroups per CU
+  const int64_t max_by_k = (K + 511) / 512;        // keep >= 512 contraction rows per split
+  if (s > max_by_k) s = max_by_k;
+  if (s < 1) s = 1;
+  if (s > 64) s = 64;
+  return (int)s;
+}
+
+}  // namespace csn
+
+using namespace csn;
+
+extern "C" int csn_gemm_nt(const void* A, const void* Bt, const float* bias, void* C, int64_t M, int64_t N, int64_t K,
+                           int dtype, int out_dtype, int accumulate, csnStream_t stream) {
+  CSN_REQUIRE(A && Bt && C, "csn_gemm_nt: null pointer");
+  CSN_REQUIRE(M > 0 && N > 0 && K > 0, "csn_gemm_nt: bad shape M=%lld N=%lld K=%lld", (long long)M, (long long)N,
+              (long long)K);
+  CSN_REQUIRE(dtype == CSN_F32 || dtype == CSN_BF16, "csn_gemm_nt: bad dtype %d", dtype);
+  CSN_REQUIRE(out_dtype == CSN_F32 || out_dtype == CSN_BF16, "csn_gemm_nt: bad out_dtype %d", out_dtype);
+  CSN_REQUIRE(!(accumulate && out_dtype != CSN_F32), "csn_gemm_nt: accumulate needs a float32 C");
+  hipStream_t st = as_stream(stream);
+  const bool fast = dtype == CSN_BF16 && (K % 8 == 0) && (N % 4 == 0) &&
+                    ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(Bt) |
+                      reinterpret_cast<uintptr_t>(C) | reinterpret_cast<uintptr_t>(bias)) & 15) == 0 &&
+                    getenv("CSN_GEMM_GENERIC") == nullptr;
+  if (!fast)
+    return launch_generic(A, K, 1, Bt, 1, K, bias, C, N, M, N, K, dtype, out_dtype, accumulate, 1, 0, st);
+  dim3 grid((unsigned)((N + 127) / 128), (unsigned)((M + 127) / 128));
+  if (out_dtype == CSN_BF16)
+    gemm_nt_bf16_kernel<bf16_t><<<grid, 256, 65536, st>>>((const bf16_t*)A, (const bf16_t*)Bt, bias, (bf16_t*)C, M, N,
+                                                          K, 0);
+  else
+    gemm_nt_bf16_kernel<float><<<grid, 256, 65536, st>>>((const bf16_t*)A, (const bf16_t*)Bt, bias, (float*)C, M, N, K,
+                                                         accumulate);
+  CSN_LAUNCH_CHECK();
+  return CSN_OK;
+}
+
+extern "C" size_t csn_gemm_tn_scratch_bytes(int64_t M, int64_t N, int64_t K) {
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  return (size_t)tn_splits(M, N, K) * (size_t)M * (size_t)N * sizeof(float);
+}
+
+extern "C" int csn_gemm_tn(const void* A, const void* B, float* C, int64_t M, int64_t N, int64_t K, int dtype,
+                           void* scratch, csnStream_t stream) {
+  CSN_REQUIRE(A && B && C && scratch, "csn_gemm_tn: null pointer");
+  CSN_REQUIRE(M > 0 && N > 0 && K > 0, "csn_gemm_tn: bad shape");
+  CSN_REQUIRE(dtype == CSN_F32 || dtype == CSN_BF16, "csn_gemm_tn: bad dtype %d", dtype);
+  hipStream_t st = as_stream(stream);
+  const int S = tn_splits(M, N, K);
+  int64_t kper = (K + S - 1) / S;
+  kper = (kper + 31) / 32 * 32;
+  float* slabs = (float*)scratch;
+  const bool fast = dtype == CSN_BF16 && (M % 8 == 0) && (N % 8 == 0) &&
+                    ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15) == 0 &&
+                    getenv("CSN_GEMM_GENERIC") == nullptr;
+  if (fast) {
+    dim3 grid((unsigned)((N + 127) / 128), (unsigned)((M + 127) / 128), (unsigned)S);
+    if (getenv("CSN_TN_NO_TR"))
+      gemm_tn_bf16_kernel<false><<<grid, 256, 0, st>>>((const bf16_t*)A, (const bf16_t*)B, slabs, M, N, K, kper);
+    else
+      gemm_tn_bf16_kernel<true><<<grid, 256, 0, st>>>((const bf16_t*)A, (const bf16_t*)B, slabs, M, N, K, kper);
+    CSN_LAUNCH_CHECK();
+  } else {
+    // A(m,k) = A[k*M + m], B(k,n) = B[k*N + n]
+    int rc = launch_generic(A, 1, M, B, N, 1, nullptr, slabs, N, M, N, K, dtype, CSN_F32, 0, S, M * N, st);
+    if (rc) return rc;
+  }
+  return launch_reduce_slabs(slabs, M * N, S, C, M * N, 0, st);
+}

@@ -1,0 +1,130 @@
+"""Data-parallel distillation trainer for the hot loop of
+/root/reference/LstmDistillFromDinoV2Train.py:351-375 (zero_grad -> forward -> loss ->
+backward -> optimiser step), restructured for MI355X:
+
+  * raw EEG segments [N,C,T], teacher embeddings [N,D] and labels stay resident in HBM;
+    a step gathers its batch by index on the device (no per-item Python, no JPEG decode,
+    no host->device copy, no ``.item()`` sync per step -- SURVEY.md section 7 H6);
+  * preprocessing is the fused HIP band-pass + z-score, the encoder the HIP LSTM;
+  * one process per GPU; gradients live in ONE flat float32 buffer that is all-reduced
+    (SUM, then / world) with a single RCCL collective per step over xGMI -- 31 MB for the
+    cfg2 model, so one large message instead of per-parameter buckets;
+  * sharding follows DistributedSampler semantics (rank r takes indices r::world of a
+    per-epoch permutation seeded by ``seed + epoch``).
+"""
+import math
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+from . import filters
+from .losses import CosineSimilarityLoss, FeatureDistributionLoss, HyperParams, loss_fn_kd
+
+
+def dist_info():
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+class FlatGrads:
+    """All parameter gradients as views into one contiguous float32 buffer."""
+
+    def __init__(self, params):
+        self.params = [p for p in params if p.requires_grad]
+        total = sum(p.numel() for p in self.params)
+        self.flat = torch.zeros(total, dtype=torch.float32, device=self.params[0].device)
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            p.grad = self.flat[off:off + n].view_as(p)
+            off += n
+
+    def zero(self):
+        self.flat.zero_()
+
+    def all_reduce_mean(self):
+        rank, world = dist_info()
+        if world > 1:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+            self.flat.div_(world)
+
+
+def shard_indices(n, epoch, seed, rank, world, shuffle=True, device="cpu"):
+    """DistributedSampler semantics: pad to a multiple of world, rank takes r::world."""
+    if shuffle:
+        g = torch.Generator()
+        g.manual_seed(seed + epoch)
+        idx = torch.randperm(n, generator=g)
+    else:
+        idx = torch.arange(n)
+    total = int(math.ceil(n / world)) * world
+    if total > n:
+        idx = torch.cat([idx, idx[: total - n]])
+    return idx[rank:total:world].to(device)
+
+
+class DistillTrainer:
+    def __init__(self, model, sos, ddof=0, loss="cosine", lr=1e-3, optimizer="rmsprop", nepochs=100,
+                 kd_params=None, preprocess=True):
+        self.model = model
+        self.sos, self.ddof, self.preprocess = sos, ddof, preprocess
+        self.loss_name = loss
+        self.grads = FlatGrads(model.parameters())
+        params = self.grads.params
+        if optimizer == "rmsprop":      # LstmDistillFromDinoV2Train.py:329
+            self.opt = torch.optim.RMSprop(params, lr=lr)
+        elif optimizer == "adamw":      # LstmDistillFromDinoV2TrainSpampinato.py:378
+            self.opt = torch.optim.AdamW(params, lr=lr)
+        elif optimizer == "adam":       # LSTMDistill.py:322
+            self.opt = torch.optim.Adam(params, lr=lr)
+        else:
+            raise ValueError(optimizer)
+        self.cosine = CosineSimilarityLoss()
+        self.featdist = FeatureDistributionLoss(nepochs, HyperParams.warmup_teacher_temp, HyperParams.teacher_temp,
+                                                HyperParams.warmup_teacher_temp_epochs)
+        self.kd_params = kd_params
+        rank, world = dist_info()
+        if world > 1:   # identical initial weights on every rank
+            for p in model.parameters():
+                dist.broadcast(p.data, src=0)
+
+    def embed(self, eeg_bct):
+        """raw EEG [B,C,T] (device, float32) -> model input [B,T,C]."""
+        if self.preprocess:
+            return filters.eeg_bandpass_znorm(eeg_bct, self.sos, ddof=self.ddof)
+        return eeg_bct.transpose(1, 2).contiguous()
+
+    def compute_loss(self, out, targets, labels, epoch):
+        if self.loss_name == "cosine":
+            feat = out[0] if isinstance(out, tuple) else out
+            return self.cosine(feat, targets)
+        if self.loss_name == "featdist":
+            feat, cls = out
+            return self.featdist(feat, targets, epoch, labels, pred_label=cls)
+        if self.loss_name == "kd":
+            feat = out[0] if isinstance(out, tuple) else out
+            return loss_fn_kd(feat, labels, targets, self.kd_params)
+        raise ValueError(self.loss_name)
+
+    def train_step(self, eeg_bct, targets, labels=None, epoch=0):
+        """One optimisation step on this rank's shard of the global batch; returns the (device) loss."""
+        self.model.train()
+        self.grads.zero()
+        x = self.embed(eeg_bct)
+        out = self.model(x)
+        loss = self.compute_loss(out, targets, labels, epoch)
+        loss.backward()
+        self.grads.all_reduce_mean()
+        self.opt.step()
+        return loss.detach()
+
+    @torch.no_grad()
+    def embed_all(self, eeg_all, batch):
+        self.model.eval()
+        outs = []
+        for i in range(0, eeg_all.shape[0], batch):
+            o = self.model(self.embed(eeg_all[i:i + batch]))
+            outs.append((o[0] if isinstance(o, tuple) else o).float())
+        return torch.cat(outs)

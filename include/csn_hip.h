@@ -1,0 +1,160 @@
+/*
+ * csn_hip.h -- C ABI of libcsn_hip.so: the MI355X (gfx950) implementation of the
+ * EEG -> stacked-LSTM -> distillation hot path of Vi-Sri/CerebralSignalNetworks.
+ *
+ * The reference is pure Python and has no FFI/plugin interface of its own (SURVEY.md
+ * section 8b): its boundary is a set of Python call sites that reach third-party native code
+ * (scipy.signal, torch.nn.LSTM/ATen, faiss).  Each entry point below replaces one of
+ * those call sites and cites it.  Signatures carry only plain pointers and sizes:
+ * every `const T*` / `T*` is a DEVICE pointer unless marked [host]; `stream` is a
+ * hipStream_t passed as void* (NULL = the default stream).  All work is enqueued on
+ * `stream`; nothing synchronises the device.  Return value: 0 on success, non-zero
+ * csnStatus otherwise, with a message in csn_last_error().  Shape / alignment
+ * violations are rejected on the host before any launch.
+ *
+ * Tensors are dense row-major unless strides are given.  dtype codes: CSN_F32, CSN_BF16.
+ */
+#ifndef CSN_HIP_H
+#define CSN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* csnStream_t;
+
+enum csnStatus {
+  CSN_OK = 0,
+  CSN_ERR_INVALID_ARGUMENT = 1,
+  CSN_ERR_HIP = 2,
+  CSN_ERR_UNSUPPORTED = 3
+};
+
+enum csnDtype { CSN_F32 = 0, CSN_BF16 = 1 };
+
+/* ABI version of this header; bumped on any signature change. */
+#define CSN_ABI_VERSION 1
+int csn_abi_version(void);
+/* Thread-local message for the last non-zero status returned on this thread. */
+const char* csn_last_error(void);
+/* Name of the device code object's target ("gfx950"). */
+const char* csn_target_arch(void);
+
+/* ------------------------------------------------------------------------------------
+ * K1+K2  fused band-pass + per-channel z-score.
+ * Replaces: scipy.signal.butter/lfilter design+apply named by utils/EEGFilters.py:2,26
+ * (applied causally, in second-order sections) followed by EEGDataset.normlizeEEG,
+ * utils/PerilsEEGDataset.py:454-461, for every channel of a segment, and the
+ * `.t()` re-layout of EEGDataset.__getitem__, utils/PerilsEEGDataset.py:549.
+ *   x      [B,C,T] float32 (channel-first, as stored on disk: ConvertToPth.py:170-201)
+ *   sos    [host] [nsec,6] float64 rows (b0,b1,b2,a0,a1,a2), nsec <= 8; nsec == 0 = no filter
+ *   ddof   0 (numpy path, PerilsEEGDataset.py:555-562) or 1 (torch path, :576-579)
+ *   y      out_dtype, laid out [B,T,C] (time_major=0) or [T,B,C] (time_major=1)
+ * IIR state and statistics are carried in float64.
+ * ---------------------------------------------------------------------------------- */
+int csn_eeg_bandpass_znorm(const float* x, int B, int C, int T,
+                           const double* sos, int nsec, int ddof,
+                           void* y, int out_dtype, int time_major, csnStream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * K3  stacked LSTM, zero initial state, gate order i,f,g,o, nn.LSTM parameter layout.
+ * Replaces: nn.LSTM(input, hidden, num_layers, batch_first=True) forward/backward at
+ * LSTMDistill.py:118,132 and LSTMDistillRetreival.py:91,103 (the body of the absent
+ * models.lstm.Model, LstmDistillFromDinoV2Train.py:323).
+ * ---------------------------------------------------------------------------------- */
+typedef struct csnLstmDesc {
+  int32_t B;      /* batch                                       */
+  int32_t T;      /* time steps                                  */
+  int32_t I;      /* input features (EEG channels)               */
+  int32_t H;      /* hidden size; multiple of 32                 */
+  int32_t L;      /* stacked layers, 1..8                        */
+  int32_t dtype;  /* CSN_BF16: bf16 MFMA operands, f32 accumulate/state; CSN_F32: exact f32 MFMA */
+} csnLstmDesc;
+
+/* Bytes of device scratch the forward (+ backward if training) needs; 256-B aligned base. */
+size_t csn_lstm_workspace_bytes(const csnLstmDesc* d, int training);
+
+/* x: element (b,t,i) at x[b*x_stride_b + t*x_stride_t + i] (float32).
+ * w_ih/w_hh/b_ih/b_hh: [host] arrays of L device pointers to float32 parameters
+ *   weight_ih_l{k}[4H,I_k], weight_hh_l{k}[4H,H], bias_ih_l{k}[4H], bias_hh_l{k}[4H].
+ * y_last: [B,H] float32 = output of the top layer at t = T-1.
+ * y_all : optional (may be NULL) [B,T,H] float32, every step of the top layer.
+ * The workspace keeps what csn_lstm_backward needs when training != 0. */
+int csn_lstm_forward(const csnLstmDesc* d,
+                     const float* x, int64_t x_stride_b, int64_t x_stride_t,
+                     const float* const* w_ih, const float* const* w_hh,
+                     const float* const* b_ih, const float* const* b_hh,
+                     void* workspace, int training,
+                     float* y_last, float* y_all, csnStream_t stream);
+
+/* dy_last: [B,H] float32 gradient w.r.t. y_last (may be NULL).
+ * dy_all : optional [B,T,H] float32 gradient w.r.t. y_all (may be NULL).
+ * dw_ih/dw_hh/db_ih/db_hh: [host] arrays of L device pointers, float32, OVERWRITTEN.
+ * dx: optional [B,T,I] float32 (dense), gradient w.r.t. x (may be NULL). */
+int csn_lstm_backward(const csnLstmDesc* d,
+                      const float* dy_last, const float* dy_all,
+                      void* workspace,
+                      float* const* dw_ih, float* const* dw_hh,
+                      float* const* db_ih, float* const* db_hh,
+                      float* dx, csnStream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Building blocks of K3, exported so that each can be parity-tested on its own.
+ * ---------------------------------------------------------------------------------- */
+/* C[M,N] (+)= A[M,K] * Bt[N,K]^T (+ bias[N]).  dtype = type of A and Bt; C is out_dtype.
+ * accumulate != 0 adds into C (float32 C only).  Replaces the input-projection /
+ * input-gradient GEMMs inside ATen's LSTM. */
+int csn_gemm_nt(const void* A, const void* Bt, const float* bias, void* C,
+                int64_t M, int64_t N, int64_t K, int dtype, int out_dtype, int accumulate,
+                csnStream_t stream);
+/* C[M,N] = A[K,M]^T * B[K,N]  (weight-gradient form; float32 C, overwritten).
+ * scratch: device buffer of csn_gemm_tn_scratch_bytes(M,N,K) bytes (split-K slabs). */
+size_t csn_gemm_tn_scratch_bytes(int64_t M, int64_t N, int64_t K);
+int csn_gemm_tn(const void* A, const void* B, float* C,
+                int64_t M, int64_t N, int64_t K, int dtype, void* scratch, csnStream_t stream);
+
+/* One LSTM cell step.  h_prev/h_out/gates are `dtype`; xproj (= x_t W_ih^T + b_ih + b_hh),
+ * c_prev, c_out float32.  gates_out (may be NULL) receives post-activation i,f,g,o [B,4H]. */
+int csn_lstm_cell_forward(const void* h_prev, const void* w_hh, const float* xproj, int64_t xproj_ld,
+                          const float* c_prev, void* gates_out, float* c_out, void* h_out,
+                          int B, int H, int dtype, csnStream_t stream);
+/* One backward cell step: dh = dy + dgates_next * W_hh (w_hh_t = W_hh^T [H,4H]); writes
+ * dgates_out [B,4H] and updates dc_carry [B,H] in place.  dgates_next / dy may be NULL. */
+int csn_lstm_cell_backward(const void* dgates_next, const void* w_hh_t,
+                           const float* dy, int64_t dy_ld,
+                           const void* gates, const float* c, const float* c_prev,
+                           float* dc_carry, void* dgates_out,
+                           int B, int H, int dtype, csnStream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * K5  1 - mean_b cos(student_b, teacher_b), dim=1, eps=1e-8, and its gradient.
+ * Replaces: CosineSimilarityLoss.forward, LstmDistillFromDinoV2Train.py:36-43.
+ *   loss: [1] float32; dstudent: optional [B,D] float32 = grad_scale * dloss/dstudent.
+ * ---------------------------------------------------------------------------------- */
+int csn_cosine_loss(const float* student, const float* teacher, int B, int D,
+                    float* loss, float* dstudent, float grad_scale, csnStream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * K7  Barlow-Twins reduction over the cross-correlation matrix c[D,D] (float32):
+ *   out[0] = sum_i (c_ii - 1)^2,  out[1] = sum_{i!=j} c_ij^2      (float32[2])
+ * Replaces: EEG-BarlowNetworks/net.py:6-9,39-40.
+ * ---------------------------------------------------------------------------------- */
+int csn_barlow_offdiag_sqsum(const float* c, int D, float* out, csnStream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * K8  exact squared-L2 top-k.  Replaces: faiss.IndexFlatL2(d).add / .search(k),
+ * utils/Utilities.py:45-55.  gallery [Ng,D], query [Nq,D] float32; out_idx [Nq,k]
+ * int64, out_dist [Nq,k] float32, ascending, ties -> lower gallery index.
+ * scratch: device buffer of csn_l2_topk_scratch_bytes(Ng,Nq) bytes.  k <= 64.
+ * ---------------------------------------------------------------------------------- */
+size_t csn_l2_topk_scratch_bytes(int64_t Ng, int64_t Nq);
+int csn_l2_topk(const float* gallery, const float* query, int64_t Ng, int64_t Nq, int D, int k,
+                int64_t* out_idx, float* out_dist, void* scratch, csnStream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CSN_HIP_H */

@@ -1,0 +1,383 @@
+"""GPU parity tests: every HIP entry point, called through the C ABI, against the CPU oracle on
+the same seeded inputs and against the committed golden vectors.  Run with ``-m gpu``.
+
+Tolerances (written here, per the north star): float32 path -- distill loss within 1e-4 of the
+oracle, gradients within 1e-4 relative to their scale; retrieval indices bit-exact.  The bf16
+MFMA path is characterised separately with looser bounds (bf16 operands carry 8 significant bits).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from cerebralsignalnetworks_amd import cabi, Model, LSTMModel, CosineSimilarityLoss, EEGFilters, BarlowTwinsLoss
+from cerebralsignalnetworks_amd import retrieval as hip_retrieval
+from oracle import eeg_filter, losses, lstm, retrieval
+
+pytestmark = pytest.mark.gpu
+
+
+def dev_t(a, cuda, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a)).to(cuda)
+    return t.to(dtype) if dtype is not None else t
+
+
+def bf16_round(a):
+    return torch.from_numpy(np.asarray(a, np.float32)).to(torch.bfloat16).float().numpy()
+
+
+# ----------------------------------------------------------------------------------------------
+# K1 + K2
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("order", [3, 4, 5])
+@pytest.mark.parametrize("ddof", [0, 1])
+def test_filter_znorm_matches_golden(cuda, golden, order, ddof):
+    g = golden("filter_apply.npz")
+    x = g["x"]                                                     # [2,16,500]
+    sos = eeg_filter.design_bandpass_sos(1000, order)
+    y = cabi.eeg_bandpass_znorm(dev_t(x, cuda), sos, ddof=ddof).cpu().numpy()      # [B,T,C]
+    want = np.transpose(g[f"znorm_o{order}_ddof{ddof}"], (0, 2, 1))
+    assert y.shape == want.shape
+    # float64 state on the device: only the final float32 rounding separates us from scipy
+    np.testing.assert_allclose(y, want, rtol=0, atol=2e-6)
+
+
+@pytest.mark.parametrize("B,C,T", [(3, 128, 500), (2, 96, 460), (1, 5, 461), (2, 128, 440), (1, 1, 2)])
+def test_filter_shapes_layouts_dtypes(cuda, B, C, T):
+    x = eeg_filter.synthetic_eeg(B, C, T, seed=B * 1000 + T)
+    sos = eeg_filter.design_bandpass_sos(1000, 3)
+    want = eeg_filter.eeg_bandpass_znorm(x, sos, ddof=0)            # [B,T,C] f64
+    xt = dev_t(x, cuda)
+    y = cabi.eeg_bandpass_znorm(xt, sos).cpu().numpy()
+    np.testing.assert_allclose(y, want, atol=5e-6)
+    y_tm = cabi.eeg_bandpass_znorm(xt, sos, time_major=True).cpu().numpy()
+    np.testing.assert_array_equal(y_tm, np.transpose(y, (1, 0, 2)))
+    y_bf = cabi.eeg_bandpass_znorm(xt, sos, out_dtype=torch.bfloat16).float().cpu().numpy()
+    np.testing.assert_array_equal(y_bf, bf16_round(y))
+    # no filter sections: pure per-channel z-score (normlizeEEG)
+    z = cabi.eeg_bandpass_znorm(xt, None, ddof=1).cpu().numpy()
+    np.testing.assert_allclose(z, np.transpose(eeg_filter.zscore_rows(x, 1), (0, 2, 1)), atol=5e-6)
+
+
+def test_filter_is_linear_and_idempotent_in_znorm_at_full_size(cuda):
+    """Size-independent properties at the benchmark shape (B=256 is too slow for the python oracle):
+    z-scored output has mean 0 / std 1 per row, and scaling the input leaves it unchanged."""
+    x = torch.from_numpy(eeg_filter.synthetic_eeg(256, 128, 500, seed=5)).to(cuda)
+    sos = eeg_filter.design_bandpass_sos(1000, 3)
+    y = cabi.eeg_bandpass_znorm(x, sos)                            # [B,T,C]
+    m = y.double().mean(dim=1)
+    s = y.double().std(dim=1, unbiased=False)
+    assert m.abs().max().item() < 1e-6 and (s - 1).abs().max().item() < 1e-6
+    y2 = cabi.eeg_bandpass_znorm(x * 3.5 , sos)
+    assert (y - y2).abs().max().item() < 1e-5
+    # spot-check 4 segments against the oracle
+    want = eeg_filter.eeg_bandpass_znorm(x[:4].cpu().numpy(), sos)
+    np.testing.assert_allclose(y[:4].cpu().numpy(), want, atol=5e-6)
+
+
+# ----------------------------------------------------------------------------------------------
+# GEMM building blocks
+# ----------------------------------------------------------------------------------------------
+def test_mfma_layout_identity_times_asymmetric(cuda):
+    """A = I with an asymmetric B catches a transposed C write or a swapped fragment map."""
+    n = 128
+    a = np.eye(n, dtype=np.float32)
+    b = (np.arange(n)[:, None] * 3 + np.arange(n)[None, :] * 0.25).astype(np.float32) / 64.0   # Bt[N,K]
+    for dt in (torch.float32, torch.bfloat16):
+        c = cabi.gemm_nt(dev_t(a, cuda, dt), dev_t(b, cuda, dt)).cpu().numpy()
+        want = a @ (bf16_round(b) if dt == torch.bfloat16 else b).T
+        np.testing.assert_allclose(c, want, atol=1e-6)
+        c2 = cabi.gemm_tn(dev_t(a, cuda, dt), dev_t(b, cuda, dt)).cpu().numpy()      # A^T B = B
+        np.testing.assert_allclose(c2, bf16_round(b) if dt == torch.bfloat16 else b, atol=1e-6)
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 384, 128), (300, 260, 72), (128, 128, 64), (64, 3072, 768), (70, 52, 40)])
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
+def test_gemm_nt(cuda, M, N, K, dt):
+    rng = np.random.default_rng(M + N + K)
+    a = rng.standard_normal((M, K)).astype(np.float32)
+    b = rng.standard_normal((N, K)).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    if dt == torch.bfloat16:
+        a, b = bf16_round(a), bf16_round(b)
+    want = a.astype(np.float64) @ b.astype(np.float64).T + bias
+    c = cabi.gemm_nt(dev_t(a, cuda, dt), dev_t(b, cuda, dt), dev_t(bias, cuda)).cpu().numpy()
+    np.testing.assert_allclose(c, want, atol=2e-4 * np.sqrt(K))
+    cb = cabi.gemm_nt(dev_t(a, cuda, dt), dev_t(b, cuda, dt), dev_t(bias, cuda), out_dtype=torch.bfloat16)
+    np.testing.assert_allclose(cb.float().cpu().numpy(), want, rtol=1e-2, atol=1e-1)
+    acc = dev_t(np.ones((M, N), np.float32), cuda)
+    cabi.gemm_nt(dev_t(a, cuda, dt), dev_t(b, cuda, dt), None, out=acc, accumulate=True)
+    np.testing.assert_allclose(acc.cpu().numpy(), want - bias + 1.0, atol=2e-4 * np.sqrt(K))
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 128, 512), (384, 96, 1000), (3072, 768, 2048), (72, 40, 333)])
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
+def test_gemm_tn(cuda, M, N, K, dt):
+    rng = np.random.default_rng(M * 7 + N + K)
+    a = rng.standard_normal((K, M)).astype(np.float32)
+    b = rng.standard_normal((K, N)).astype(np.float32)
+    if dt == torch.bfloat16:
+        a, b = bf16_round(a), bf16_round(b)
+    want = a.astype(np.float64).T @ b.astype(np.float64)
+    c = cabi.gemm_tn(dev_t(a, cuda, dt), dev_t(b, cuda, dt)).cpu().numpy()
+    np.testing.assert_allclose(c, want, atol=2e-4 * np.sqrt(K))
+    if dt == torch.bfloat16:
+        # the transposed-LDS-read kernel and the scalar-read kernel must agree bit for bit
+        os.environ["CSN_TN_NO_TR"] = "1"
+        try:
+            c2 = cabi.gemm_tn(dev_t(a, cuda, dt), dev_t(b, cuda, dt)).cpu().numpy()
+        finally:
+            del os.environ["CSN_TN_NO_TR"]
+        np.testing.assert_array_equal(c, c2)
+        c_run2 = cabi.gemm_tn(dev_t(a, cuda, dt), dev_t(b, cuda, dt)).cpu().numpy()
+        np.testing.assert_array_equal(c, c_run2)          # split-K combine is order-fixed
+
+
+# ----------------------------------------------------------------------------------------------
+# K3: cell steps, full sequence
+# ----------------------------------------------------------------------------------------------
+def _sig(x):
+    return 1 / (1 + np.exp(-x))
+
+
+@pytest.mark.parametrize("B,H", [(4, 64), (70, 96), (256, 768)])
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_cell_forward_backward_step(cuda, B, H, dt):
+    rng = np.random.default_rng(B + H)
+    k = 1 / np.sqrt(H)
+    w = rng.uniform(-k, k, (4 * H, H)).astype(np.float32)
+    h0 = rng.uniform(-1, 1, (B, H)).astype(np.float32)
+    c0 = rng.standard_normal((B, H)).astype(np.float32)
+    xp = rng.standard_normal((B, 4 * H)).astype(np.float32)
+    if dt == torch.bfloat16:
+        w, h0 = bf16_round(w), bf16_round(h0)
+    a = xp.astype(np.float64) + h0.astype(np.float64) @ w.astype(np.float64).T
+    i, f, g, o = _sig(a[:, :H]), _sig(a[:, H:2 * H]), np.tanh(a[:, 2 * H:3 * H]), _sig(a[:, 3 * H:])
+    c1 = f * c0 + i * g
+    h1 = o * np.tanh(c1)
+    hd, cd, gd = cabi.lstm_cell_forward(dev_t(h0, cuda, dt), dev_t(w, cuda, dt), dev_t(xp, cuda), dev_t(c0, cuda))
+    tol = 2e-6 if dt == torch.float32 else 1e-2
+    np.testing.assert_allclose(cd.cpu().numpy(), c1, atol=2e-6 if dt == torch.float32 else 2e-5)
+    np.testing.assert_allclose(hd.float().cpu().numpy(), h1, atol=tol)
+    np.testing.assert_allclose(gd.float().cpu().numpy(), np.concatenate([i, f, g, o], 1), atol=tol)
+    # zero initial state: null h_prev / c_prev
+    hz, cz, _ = cabi.lstm_cell_forward(None, dev_t(w, cuda, dt), dev_t(xp, cuda), None)
+    a0 = xp.astype(np.float64)
+    cz_ref = _sig(a0[:, :H]) * np.tanh(a0[:, 2 * H:3 * H])
+    np.testing.assert_allclose(cz.cpu().numpy(), cz_ref, atol=2e-6)
+
+    # backward step against the oracle formulas
+    dgn = (rng.standard_normal((B, 4 * H)) * 0.1).astype(np.float32)
+    dy = rng.standard_normal((B, H)).astype(np.float32)
+    dcn = rng.standard_normal((B, H)).astype(np.float32)
+    gates = np.concatenate([i, f, g, o], 1).astype(np.float32)
+    if dt == torch.bfloat16:
+        dgn, gates = bf16_round(dgn), bf16_round(gates)
+    gi, gf, gg, go = (gates[:, j * H:(j + 1) * H].astype(np.float64) for j in range(4))
+    c1f = c1.astype(np.float32).astype(np.float64)
+    dh = dy + dgn.astype(np.float64) @ w.astype(np.float64)
+    tc = np.tanh(c1f)
+    dc = dh * go * (1 - tc * tc) + dcn
+    want = np.concatenate([dc * gg * gi * (1 - gi), dc * c0 * gf * (1 - gf), dc * gi * (1 - gg * gg),
+                           dh * tc * go * (1 - go)], 1)
+    wt = np.ascontiguousarray(w.T)
+    dcar = dev_t(dcn, cuda)
+    out = cabi.lstm_cell_backward(dev_t(dgn, cuda, dt), dev_t(wt, cuda, dt), dev_t(dy, cuda), dev_t(gates, cuda, dt),
+                                  dev_t(c1.astype(np.float32), cuda), dev_t(c0, cuda), dcar)
+    np.testing.assert_allclose(out.float().cpu().numpy(), want, atol=1e-5 if dt == torch.float32 else 2e-2)
+    np.testing.assert_allclose(dcar.cpu().numpy(), dc * gf, atol=1e-5)
+
+
+def _model_from_params(p, C, H, L, D, NC, dtype, cuda):
+    m = Model(input_size=C, lstm_size=H, lstm_layers=L, output_size=D, include_top=bool(NC), n_classes=NC or 40,
+              compute_dtype=dtype)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in p.items()})
+    return m.to(cuda)
+
+
+def test_lstm_model_matches_torch_golden_f32(cuda, golden):
+    """Full path on the small golden: outputs, loss (<= 1e-4) and every gradient vs torch.nn.LSTM."""
+    g = golden("lstm_small.npz")
+    B, T, C, H, L, D, NC = (int(v) for v in g["dims"])
+    p = {k[len("param__"):]: g[k] for k in g.files if k.startswith("param__")}
+    m = _model_from_params(p, C, H, L, D, NC, torch.float32, cuda)
+    feat, cls = m(dev_t(g["x"], cuda))
+    loss = CosineSimilarityLoss()(feat, dev_t(g["target"], cuda))
+    loss.backward()
+    np.testing.assert_allclose(feat.detach().cpu().numpy(), g["feat_f64"], atol=5e-6)
+    np.testing.assert_allclose(cls.detach().cpu().numpy(), g["cls_f64"], atol=5e-6)
+    assert abs(loss.item() - float(g["loss_f64"])) < 1e-4
+    assert abs(loss.item() - float(g["loss_f32"])) < 1e-5
+    for name, par in m.named_parameters():
+        key = f"grad_f64__{name}"
+        if key in g.files:
+            want = g[key]
+            scale = max(1e-3, np.abs(want).max())
+            np.testing.assert_allclose(par.grad.cpu().numpy(), want, atol=1e-4 * scale, err_msg=name)
+
+
+def test_lstm_all_steps_and_input_grad_f32(cuda):
+    rng = np.random.default_rng(0)
+    B, T, C, H, L = 3, 20, 24, 32, 3
+    p = lstm.init_params(C, H, L, 8, None, seed=9)
+    lp = {k[len("lstm."):]: v for k, v in p.items() if k.startswith("lstm.")}
+    x = rng.standard_normal((B, T, C)).astype(np.float32)
+    dy = rng.standard_normal((B, T, H)).astype(np.float32)
+    y, saved = lstm.lstm_forward(x, lp, L, return_saved=True)
+    dx_ref, g_ref = lstm.lstm_backward(dy, lp, saved, L)
+    m = _model_from_params(p, C, H, L, 8, None, torch.float32, cuda)
+    xt = dev_t(x, cuda).requires_grad_(True)
+    y_all, y_last = m.lstm(xt, want_all=True)
+    np.testing.assert_allclose(y_all.detach().cpu().numpy(), y, atol=5e-6)
+    np.testing.assert_allclose(y_last.detach().cpu().numpy(), y[:, -1], atol=5e-6)
+    (y_all * dev_t(dy, cuda)).sum().backward()
+    np.testing.assert_allclose(xt.grad.cpu().numpy(), dx_ref, atol=2e-5)
+    for k, v in g_ref.items():
+        got = getattr(m.lstm, k).grad.cpu().numpy()
+        np.testing.assert_allclose(got, v, atol=1e-4 * max(1.0, np.abs(v).max()), err_msg=k)
+
+
+def test_lstm_full_size_forward_f32_and_bf16(cuda, golden):
+    g = golden("lstm_full_fwd.npz")
+    B, T, C, H, L, D = (int(v) for v in g["dims"])
+    p = lstm.init_params(C, H, L, D, None, seed=int(g["seed_params"]))
+    x = np.random.default_rng(int(g["seed_x"])).standard_normal((B, T, C)).astype(np.float32)
+    with torch.no_grad():
+        m = _model_from_params(p, C, H, L, D, None, torch.float32, cuda)
+        feat = m(dev_t(x, cuda)).cpu().numpy()
+        np.testing.assert_allclose(feat, g["feat"], atol=2e-5)
+        mb = _model_from_params(p, C, H, L, D, None, torch.bfloat16, cuda)
+        featb = mb(dev_t(x, cuda)).cpu().numpy()
+    # bf16 operands over 500 recurrent steps x 2 layers: characterised, not bit-tight
+    err = np.abs(featb - g["feat"]).max()
+    assert err < 3e-2, err
+    cos = (featb * g["feat"]).sum(1) / np.linalg.norm(featb, axis=1) / np.linalg.norm(g["feat"], axis=1)
+    assert cos.min() > 0.999
+
+
+def test_bf16_training_step_tracks_f32(cuda):
+    rng = np.random.default_rng(4)
+    B, T, C, H, L, D = 16, 48, 32, 64, 2, 32
+    p = lstm.init_params(C, H, L, D, None, seed=3)
+    x = rng.standard_normal((B, T, C)).astype(np.float32)
+    tgt = rng.standard_normal((B, D)).astype(np.float32)
+    res = {}
+    for dt in (torch.float32, torch.bfloat16):
+        m = _model_from_params(p, C, H, L, D, None, dt, cuda)
+        loss = CosineSimilarityLoss()(m(dev_t(x, cuda)), dev_t(tgt, cuda))
+        loss.backward()
+        res[dt] = (loss.item(), {n: q.grad.cpu().numpy() for n, q in m.named_parameters()})
+    feat, saved = lstm.model_forward(x, p, L, return_saved=True)
+    assert abs(res[torch.float32][0] - losses.cosine_similarity_loss(feat, tgt)) < 1e-5
+    assert abs(res[torch.bfloat16][0] - res[torch.float32][0]) < 5e-3
+    for n, gf in res[torch.float32][1].items():
+        gb = res[torch.bfloat16][1][n]
+        rel = np.linalg.norm(gb - gf) / max(1e-12, np.linalg.norm(gf))
+        assert rel < 5e-2, (n, rel)
+
+
+def test_reference_view_quirk_lstmmodel(cuda):
+    """LSTMDistillRetreival.LSTMModel: x.view(B, C, T) is a reshape, sequence runs over channels."""
+    rng = np.random.default_rng(1)
+    B, T, C, H = 2, 32, 6, 32
+    m = LSTMModel(input_size=T, hidden_size=H, n_layers=2, out_features=8, compute_dtype=torch.float32).to(cuda)
+    x = rng.standard_normal((B, T, C)).astype(np.float32)
+    p = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
+    want = lstm.model_forward(x.reshape(B, C, T), p, 2)
+    with torch.no_grad():
+        got = m(dev_t(x, cuda)).cpu().numpy()
+    np.testing.assert_allclose(got, want, atol=5e-6)
+
+
+# ----------------------------------------------------------------------------------------------
+# K5 / K7 / K8
+# ----------------------------------------------------------------------------------------------
+def test_cosine_loss_and_grad(cuda, golden):
+    g = golden("losses.npz")
+    s = dev_t(g["student"], cuda).requires_grad_(True)
+    loss = CosineSimilarityLoss()(s, dev_t(g["teacher"], cuda))
+    loss.backward()
+    assert abs(loss.item() - float(g["cosine_loss"])) < 1e-6
+    np.testing.assert_allclose(s.grad.cpu().numpy(), g["cosine_grad"], atol=1e-8)
+
+
+def test_barlow_reduction(cuda, golden):
+    g = golden("losses.npz")
+    out = cabi.barlow_offdiag_sqsum(dev_t(g["barlow_c"].astype(np.float32), cuda)).cpu().numpy()
+    np.testing.assert_allclose(out, [float(g["barlow_on"]), float(g["barlow_off"])], rtol=1e-5)
+    z1 = dev_t(g["barlow_z1"].astype(np.float32), cuda).requires_grad_(True)
+    z2 = dev_t(g["barlow_z2"].astype(np.float32), cuda)
+    crit = BarlowTwinsLoss(96, 32).to(cuda)
+    loss = crit(z1, z2)
+    loss.backward()
+    assert abs(loss.item() - float(g["barlow_loss"])) < 1e-3 * float(g["barlow_loss"])
+    # gradient against torch autograd of the reference formula
+    z1r = dev_t(g["barlow_z1"].astype(np.float32), cuda).requires_grad_(True)
+    bn = torch.nn.BatchNorm1d(96, affine=False).to(cuda)
+    c = bn(z1r).T @ bn(z2) / 32
+    ref = torch.diagonal(c).add(-1).pow(2).sum() + 0.0051 * (c.pow(2).sum() - torch.diagonal(c).pow(2).sum())
+    ref.backward()
+    np.testing.assert_allclose(z1.grad.cpu().numpy(), z1r.grad.cpu().numpy(), atol=1e-5)
+
+
+@pytest.mark.parametrize("Ng,Nq,D,k", [(200, 50, 384, 5), (1000, 257, 384, 5), (37, 3, 20, 37), (5, 2, 2, 3)])
+def test_l2_topk_indices_bit_exact(cuda, Ng, Nq, D, k):
+    rng = np.random.default_rng(Ng + Nq)
+    gal = rng.standard_normal((Ng, D)).astype(np.float32)
+    qry = rng.standard_normal((Nq, D)).astype(np.float32)
+    gal[Ng // 2] = gal[0]                       # an exact duplicate: tie must go to the lower index
+    qry[0] = gal[0]
+    Dref, Iref = retrieval.l2_topk(gal, qry, k)
+    Dg, Ig = cabi.l2_topk(dev_t(gal, cuda), dev_t(qry, cuda), k)
+    np.testing.assert_array_equal(Ig.cpu().numpy(), Iref)
+    np.testing.assert_allclose(Dg.cpu().numpy(), Dref, rtol=1e-6, atol=1e-6)
+
+
+def test_evaluate_matches_oracle_bookkeeping(cuda):
+    rng = np.random.default_rng(8)
+    names = {i: f"class{i % 37}" for i in range(40)}            # two ids share a name on purpose
+    glab = [dict(ClassId=int(c), ClassName=names[int(c)]) for c in rng.integers(0, 40, 200)]
+    qlab = [dict(ClassId=int(c), ClassName=names[int(c)]) for c in rng.integers(0, 40, 50)]
+    gal = rng.standard_normal((200, 384)).astype(np.float32)
+    qry = rng.standard_normal((50, 384)).astype(np.float32)
+
+    class DS:
+        class_id_to_str = names
+        class_str_to_id = {v: k for k, v in names.items()}
+
+    class FL:
+        topK = 5
+    r = hip_retrieval.evaluate_full(FL, list(gal), list(qry), glab, qlab, DS)
+    rec, prec, per, top1, D, I = retrieval.evaluate(gal, qry, glab, qlab, names, 5)
+    np.testing.assert_array_equal(r["I"], I)
+    assert r["Recall_Total"] == rec and r["Precision_Total"] == prec and r["top1"] == top1
+    for k2, v in per.items():
+        for f in ("TP", "classIntanceRetrival", "TotalRetrival", "TotalClass", "Recall", "Precision"):
+            assert r["class_scores"][k2][f] == v[f]
+
+
+# ----------------------------------------------------------------------------------------------
+# end to end: filter -> LSTM -> loss -> backward, one training step, vs the oracle pipeline
+# ----------------------------------------------------------------------------------------------
+def test_end_to_end_step_loss_within_1e4(cuda):
+    from cerebralsignalnetworks_amd.trainer import DistillTrainer
+    B, C, T, H, L, D = 8, 128, 500, 96, 2, 384
+    x = eeg_filter.synthetic_eeg(B, C, T, seed=43)
+    tgt = np.random.default_rng(44).standard_normal((B, D)).astype(np.float32)
+    p = lstm.init_params(C, H, L, D, None, seed=43)
+    m = _model_from_params(p, C, H, L, D, None, torch.float32, cuda)
+    filt = EEGFilters(1000, order=3)
+    tr = DistillTrainer(m, filt.sos, loss="cosine", lr=1e-3, optimizer="rmsprop")
+    loss = tr.train_step(dev_t(x, cuda), dev_t(tgt, cuda))
+    eeg_ref = eeg_filter.eeg_bandpass_znorm(x, filt.sos)
+    feat, saved = lstm.model_forward(eeg_ref, p, L, return_saved=True)
+    loss_ref = losses.cosine_similarity_loss(feat, tgt)
+    assert abs(loss.item() - loss_ref) < 1e-4, (loss.item(), loss_ref)
+    # the RMSprop update moved the weights in the direction the oracle gradient predicts
+    _, grads = lstm.model_backward(losses.cosine_similarity_loss_grad(feat, tgt), p, saved, L)
+    w_new = m.lstm.weight_hh_l1.detach().cpu().numpy()
+    step = w_new - p["lstm.weight_hh_l1"]
+    gref = grads["lstm.weight_hh_l1"]
+    big = np.abs(gref) > 1e-3 * np.abs(gref).max()
+    assert (np.sign(step[big]) == -np.sign(gref[big])).mean() > 0.999
