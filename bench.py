@@ -85,6 +85,10 @@ def time_cell_kernels(args, device, dtype):
     return out
 
 
+def log(msg):
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -113,8 +117,11 @@ def main():
         j = (i % args.pool) * B
         return trainer.train_step(x[j:j + B], tg[j:j + B], lab[j:j + B])
 
+    log(f"rank {rank}/{world}: pool resident, {args.warmup} warm-up steps")
     for i in range(args.warmup):
         step(i)
+        torch.cuda.synchronize()
+        log(f"warm-up step {i} done")
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -131,6 +138,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     final_loss = float(loss.item())
+    log(f"timed region done: {elapsed:.3f}s for {args.steps} steps")
 
     if rank == 0:
         seg_per_s = world * B * args.steps / elapsed
@@ -149,6 +157,7 @@ def main():
         }
         if not args.no_kernel_timing:
             kt = time_cell_kernels(args, device, dtype)
+            log(f"cell kernel timing: {kt}")
             # dominant kernel: the backward cell step (K = 4H per launch); algorithmic flops per launch
             fl_fwd = 2.0 * B * 4 * H * H
             fl_bwd = 2.0 * B * 4 * H * H
@@ -163,6 +172,7 @@ def main():
                                "flops_per_launch": fl_bwd if dom == "bwd" else fl_fwd}
         if world == 1 and not args.no_cpu_baseline:
             from oracle import cpu_path, eeg_filter
+            log(f"CPU baseline on {cpu_path.usable_cores()} cores")
             nb = 8
             xs = eeg_filter.synthetic_eeg(nb, C, T, seed=43)
             ts = np.random.default_rng(44).standard_normal((nb, D)).astype(np.float32)

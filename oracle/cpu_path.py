@@ -13,6 +13,27 @@ import time
 import numpy as np
 
 
+def usable_cores():
+    """Cores this process may actually use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:   # cgroup v2
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    try:   # cgroup v1
+        quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if quota > 0 and period > 0:
+            n = min(n, max(1, quota // period))
+    except (OSError, ValueError):
+        pass
+    if os.environ.get("CSN_CPU_THREADS"):
+        n = int(os.environ["CSN_CPU_THREADS"])
+    return max(1, min(n, 16))   # 16 = the CPU share of a one-GPU box in this pool
+
+
 def build_torch_reference_model(input_size, hidden, layers, out_features, n_classes=None, seed=43):
     import torch
     import torch.nn as nn
@@ -47,7 +68,7 @@ def time_cpu_train_steps(x_bct, targets, sos, hidden=768, layers=2, steps=2, war
     """Times the CPU path on a bounded sample.  Returns dict(seg_per_s, s_per_step, cores, losses)."""
     import torch
     import torch.nn as nn
-    threads = threads or os.cpu_count()
+    threads = threads or usable_cores()
     torch.set_num_threads(threads)
     B, C, T = x_bct.shape
     model = build_torch_reference_model(C, hidden, layers, targets.shape[1])
