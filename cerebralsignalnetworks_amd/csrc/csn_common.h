@@ -71,5 +71,10 @@ int launch_reduce_slabs(const float* slabs, int64_t stride, int S, float* out, i
 // out[N] = column sums of X[R,N] (dtype), deterministic; scratch >= colsum_scratch_bytes(N)
 size_t colsum_scratch_bytes(int64_t N);
 int launch_colsum(const void* X, int64_t R, int64_t N, int dtype, float* out, void* scratch, hipStream_t st);
+int colsum_chunks();
+int launch_colsum_partial(const void* X, int64_t R, int64_t N, int dtype, void* scratch, hipStream_t st);
+// split-K slabs of C[M,N] = A[K,M]^T B[K,N] into `slabs` ([S][M*N] f32); returns S through S_out
+int launch_gemm_tn_slabs(const void* A, const void* B, float* slabs, int64_t M, int64_t N, int64_t K, int dtype,
+                         hipStream_t st, int* S_out);
 
 }  // namespace csn

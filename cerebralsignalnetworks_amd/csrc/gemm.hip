@@ -395,16 +395,13 @@ extern "C" size_t csn_gemm_tn_scratch_bytes(int64_t M, int64_t N, int64_t K) {
   return (size_t)tn_splits(M, N, K) * (size_t)M * (size_t)N * sizeof(float);
 }
 
-extern "C" int csn_gemm_tn(const void* A, const void* B, float* C, int64_t M, int64_t N, int64_t K, int dtype,
-                           void* scratch, csnStream_t stream) {
-  CSN_REQUIRE(A && B && C && scratch, "csn_gemm_tn: null pointer");
-  CSN_REQUIRE(M > 0 && N > 0 && K > 0, "csn_gemm_tn: bad shape");
-  CSN_REQUIRE(dtype == CSN_F32 || dtype == CSN_BF16, "csn_gemm_tn: bad dtype %d", dtype);
-  hipStream_t st = as_stream(stream);
+namespace csn {
+int launch_gemm_tn_slabs(const void* A, const void* B, float* slabs, int64_t M, int64_t N, int64_t K, int dtype,
+                         hipStream_t st, int* S_out) {
   const int S = tn_splits(M, N, K);
   int64_t kper = (K + S - 1) / S;
   kper = (kper + 31) / 32 * 32;
-  float* slabs = (float*)scratch;
+  *S_out = S;
   const bool fast = dtype == CSN_BF16 && (M % 8 == 0) && (N % 8 == 0) &&
                     ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15) == 0 &&
                     getenv("CSN_GEMM_GENERIC") == nullptr;
@@ -415,10 +412,20 @@ extern "C" int csn_gemm_tn(const void* A, const void* B, float* C, int64_t M, in
     else
       gemm_tn_bf16_kernel<true><<<grid, 256, 0, st>>>((const bf16_t*)A, (const bf16_t*)B, slabs, M, N, K, kper);
     CSN_LAUNCH_CHECK();
-  } else {
-    // A(m,k) = A[k*M + m], B(k,n) = B[k*N + n]
-    int rc = launch_generic(A, 1, M, B, N, 1, nullptr, slabs, N, M, N, K, dtype, CSN_F32, 0, S, M * N, st);
-    if (rc) return rc;
+    return CSN_OK;
   }
-  return launch_reduce_slabs(slabs, M * N, S, C, M * N, 0, st);
+  // A(m,k) = A[k*M + m], B(k,n) = B[k*N + n]
+  return launch_generic(A, 1, M, B, N, 1, nullptr, slabs, N, M, N, K, dtype, CSN_F32, 0, S, M * N, st);
+}
+}  // namespace csn
+
+extern "C" int csn_gemm_tn(const void* A, const void* B, float* C, int64_t M, int64_t N, int64_t K, int dtype,
+                           void* scratch, csnStream_t stream) {
+  CSN_REQUIRE(A && B && C && scratch, "csn_gemm_tn: null pointer");
+  CSN_REQUIRE(M > 0 && N > 0 && K > 0, "csn_gemm_tn: bad shape");
+  CSN_REQUIRE(dtype == CSN_F32 || dtype == CSN_BF16, "csn_gemm_tn: bad dtype %d", dtype);
+  hipStream_t st = as_stream(stream);
+  int S = 1;
+  if (int rc = launch_gemm_tn_slabs(A, B, (float*)scratch, M, N, K, dtype, st, &S)) return rc;
+  return launch_reduce_slabs((const float*)scratch, M * N, S, C, M * N, 0, st);
 }

@@ -2,23 +2,31 @@
 // Replaces nn.LSTM(batch_first=True).forward / autograd backward as called at
 // /root/reference/LSTMDistill.py:118,132 and /root/reference/LSTMDistillRetreival.py:91,103.
 //
-// Layout in HBM (all inside the caller-provided workspace; [T,B,*] time-major so that one
-// timestep is one contiguous slab that the per-step cell kernel streams):
-//   per layer l:  Wih_c[4H,I_l]  Whh_c[4H,H]  WhhT_c[H,4H]  WihT_c[I_l,4H]   compute dtype copies
-//                 bias[4H] f32 (= b_ih + b_hh)
-//                 xproj[T,B,4H] f32          input projection + bias, one big GEMM per layer
-//                 gates[T,B,4H] dtype        post-activation i,f,g,o (saved for backward)
-//                 c_all[T+1,B,H] f32, h_all[T+1,B,H] dtype   (slot 0 = zero initial state)
-//                 dgates[T,B,4H] dtype       pre-activation gradients (backward)
-//   shared:       x_c[T,B,I] dtype (time-major copy of the input), dx_buf[T,B,H] f32 (gradient
-//                 flowing into the layer below), dc_carry[B,H] f32, dy_tm[T,B,H] f32 (optional),
-//                 GEMM split-K slabs, column-sum partials.
-// The recurrence is a stream of per-timestep launches on one HIP stream (a launch boundary
-// is the cheapest grid-wide hand-off on this chip, ~1.5 us); the two big
-// non-recurrent contractions per layer (input projection, weight gradients) are single GEMMs.
+// Two paths share the C entry points:
+//
+//  * "il" fast path (bf16, H % 128 == 0): lstm_cell_blk.hip kernels.  The layers advance as a
+//    WAVEFRONT: one launch per diagonal runs layer 0 at step d, layer 1 at step d - lag, ...
+//    (lag = 2 chunks), so a launch boundary (~2 us) and the launch ramp are paid once per
+//    diagonal, not once per layer-step, and a 2-layer diagonal is exactly one workgroup per CU.
+//    The non-recurrent contractions are big GEMMs on a second, library-owned HIP stream:
+//      forward : xproj_{l+1}[chunk] = h_l[chunk] W_ih^T + b   as soon as layer l finished a chunk;
+//      backward: dx_l[chunk] = dgates_l[chunk] W_ih (input gradient of layer l = dy of layer l-1),
+//                then dW_hh, dW_ih, db of layer l once its recurrence is done
+//    and HIP events order the two streams, so the MFMA-bound GEMMs run beside the
+//    latency/bandwidth-bound recurrence of the other layer instead of after it.
+//  * "v1" path (exact-f32 parity path, or shapes the fast path does not cover): layer after
+//    layer, generic cell kernels of lstm_cell.hip.
+//
+// Layout in HBM (inside the caller's workspace; [T,B,*] time-major so one timestep is one slab):
+//   per layer: compute-dtype weight copies (+ transposes / fragment-major forms), bias,
+//              xproj[T,B,4H] f32, gates[T,B,4H], c_all[T+1,B,H] f32, h_all[T+1,B,H],
+//              dgates[T,B,4H], dx[T,B,I_l] f32; fast path adds the fragment-major ping-pong
+//              buffers of h and dgates.  In the fast path every 4H axis is gate-interleaved
+//              (n' = 4 unit + gate); parameters and their gradients are (un)permuted at the API.
 #include <vector>
 
 #include "csn_common.h"
+#include "lstm_cell_blk.h"
 
 namespace csn {
 
@@ -29,15 +37,18 @@ int launch_cell_bwd(const void* dg_next, const void* w_hh_t, const float* dy, in
                     hipStream_t st);
 
 struct LayerWs {
-  size_t wih, whh, whht, wiht, bias, xproj, gates, c_all, h_all, dgates;
+  size_t wih, whh, whht, wiht, whh_blk, whht_blk, bias, xproj, gates, c_all, h_all, dgates, dx, dc_carry, hblk[2],
+      dgblk[2];
 };
 struct WsLayout {
   LayerWs layer[8];
-  size_t x_c, dx_buf[2], dc_carry, dy_tm, tn_scratch, colsum, total;
+  size_t x_c, dy_tm, tn_scratch, colsum, total;
+  bool il;
 };
 
 static WsLayout make_layout(const csnLstmDesc& d, int training) {
   WsLayout w{};
+  w.il = cell_blk_supported(d.H, d.dtype);
   size_t off = 0;
   const size_t es = dtype_size(d.dtype);
   auto take = [&](size_t bytes) {
@@ -46,30 +57,42 @@ static WsLayout make_layout(const csnLstmDesc& d, int training) {
     return o;
   };
   const size_t TB = (size_t)d.T * d.B, H = d.H, G = 4 * (size_t)d.H;
+  const size_t Bpad = ((size_t)d.B + 63) / 64 * 64;
   size_t tn_bytes = 0;
   for (int l = 0; l < d.L; ++l) {
     const size_t I = l == 0 ? d.I : d.H;
     LayerWs& L = w.layer[l];
     L.wih = take(G * I * es);
-    L.whh = take(G * H * es);
-    L.whht = take(G * H * es);
     L.wiht = take(G * I * es);
     L.bias = take(G * 4);
+    if (w.il) {
+      L.whh_blk = take(G * H * 2);
+      L.whht_blk = take(G * H * 2);
+      L.hblk[0] = take(Bpad * H * 2);
+      L.hblk[1] = take(Bpad * H * 2);
+    } else {
+      L.whh = take(G * H * es);
+      L.whht = take(G * H * es);
+    }
     L.xproj = take(TB * G * 4);
     L.gates = take(TB * G * es);
     L.c_all = take((TB + d.B) * H * 4);
     L.h_all = take((TB + d.B) * H * es);
-    L.dgates = training ? take(TB * G * es) : 0;
+    if (training) {
+      L.dgates = take(TB * G * es);
+      L.dx = take(TB * I * 4);
+      L.dc_carry = take((size_t)d.B * H * 4);
+      if (w.il) {
+        L.dgblk[0] = take(Bpad * G * 2);
+        L.dgblk[1] = take(Bpad * G * 2);
+      }
+    }
     size_t a = csn_gemm_tn_scratch_bytes(G, I, TB), b = csn_gemm_tn_scratch_bytes(G, H, TB);
     if (a > tn_bytes) tn_bytes = a;
     if (b > tn_bytes) tn_bytes = b;
   }
   w.x_c = take(TB * d.I * es);
   if (training) {
-    const size_t widest = (size_t)(d.I > d.H ? d.I : d.H);
-    w.dx_buf[0] = take(TB * widest * 4);
-    w.dx_buf[1] = take(TB * widest * 4);
-    w.dc_carry = take((size_t)d.B * H * 4);
     w.dy_tm = take(TB * H * 4);
     w.tn_scratch = take(tn_bytes);
     w.colsum = take(colsum_scratch_bytes(G));
@@ -119,7 +142,6 @@ __global__ void tb_to_bt_kernel(const float* __restrict__ src, float* __restrict
   }
 }
 
-// dst[t_sel][b][h] += src[b][h]   (adds dy_last into the time-major dy buffer)
 __global__ void add_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, int64_t n) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] += src[i];
@@ -128,6 +150,48 @@ __global__ void add_rows_kernel(const float* __restrict__ src, float* __restrict
 static inline unsigned grid_for(int64_t n) {
   int64_t g = (n + 255) / 256;
   return (unsigned)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
+}
+
+// ---- second stream + event pool (library-owned, created on first use, per device) ------------
+struct SideCtx {
+  hipStream_t side = nullptr;
+  std::vector<hipEvent_t> events;
+  size_t next = 0;
+};
+static SideCtx g_side[16];
+
+static int side_ctx(SideCtx** out) {
+  int dev = 0;
+  CSN_HIP_CHECK(hipGetDevice(&dev));
+  CSN_REQUIRE(dev >= 0 && dev < 16, "device index %d out of range", dev);
+  SideCtx& c = g_side[dev];
+  if (c.side == nullptr) CSN_HIP_CHECK(hipStreamCreateWithFlags(&c.side, hipStreamNonBlocking));
+  c.next = 0;
+  *out = &c;
+  return CSN_OK;
+}
+static int next_event(SideCtx* c, hipEvent_t* ev) {
+  if (c->next == c->events.size()) {
+    hipEvent_t e;
+    CSN_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    c->events.push_back(e);
+  }
+  *ev = c->events[c->next++];
+  return CSN_OK;
+}
+// record on `from`, make `to` wait
+static int hand_off(SideCtx* c, hipStream_t from, hipStream_t to) {
+  hipEvent_t ev;
+  if (int rc = next_event(c, &ev)) return rc;
+  CSN_HIP_CHECK(hipEventRecord(ev, from));
+  CSN_HIP_CHECK(hipStreamWaitEvent(to, ev, 0));
+  return CSN_OK;
+}
+
+static int chunk_steps() {
+  const char* e = getenv("CSN_LSTM_CHUNK");
+  int c = e ? atoi(e) : 32;
+  return c < 1 ? 1 : c;
 }
 
 }  // namespace csn
@@ -139,6 +203,284 @@ extern "C" size_t csn_lstm_workspace_bytes(const csnLstmDesc* d, int training) {
   return make_layout(*d, training).total;
 }
 
+// =============================================================================================
+// v1 path
+// =============================================================================================
+static int forward_v1(const csnLstmDesc* d, const WsLayout& w, char* ws, const float* x, int64_t xsb, int64_t xst,
+                      const float* const* w_ih, const float* const* w_hh, const float* const* b_ih,
+                      const float* const* b_hh, int training, csnStream_t stream) {
+  hipStream_t st = as_stream(stream);
+  const int B = d->B, T = d->T, H = d->H, dt = d->dtype;
+  const int64_t G = 4 * (int64_t)H, TB = (int64_t)T * B;
+  const size_t es = dtype_size(dt);
+  int rc;
+  if ((rc = launch_cast_strided(x, xsb, xst, B, T, d->I, ws + w.x_c, dt, st))) return rc;
+  for (int l = 0; l < d->L; ++l) {
+    const LayerWs& L = w.layer[l];
+    const int64_t I = l == 0 ? d->I : H;
+    if ((rc = launch_cast(w_ih[l], ws + L.wih, G * I, dt, st))) return rc;
+    if ((rc = launch_cast(w_hh[l], ws + L.whh, G * H, dt, st))) return rc;
+    if (training) {
+      if ((rc = launch_transpose_cast(w_hh[l], G, H, ws + L.whht, dt, st))) return rc;
+      if ((rc = launch_transpose_cast(w_ih[l], G, I, ws + L.wiht, dt, st))) return rc;
+    }
+    if ((rc = launch_add_vec(b_ih[l], b_hh[l], (float*)(ws + L.bias), G, st))) return rc;
+    const void* inp = l == 0 ? (const void*)(ws + w.x_c)
+                             : (const void*)(ws + w.layer[l - 1].h_all + (size_t)B * H * es);
+    if ((rc = csn_gemm_nt(inp, ws + L.wih, (const float*)(ws + L.bias), ws + L.xproj, TB, G, I, dt, CSN_F32, 0,
+                          stream)))
+      return rc;
+    CSN_HIP_CHECK(hipMemsetAsync(ws + L.h_all, 0, (size_t)B * H * es, st));
+    CSN_HIP_CHECK(hipMemsetAsync(ws + L.c_all, 0, (size_t)B * H * 4, st));
+    for (int t = 0; t < T; ++t) {
+      rc = launch_cell_fwd(ws + L.h_all + (size_t)t * B * H * es, ws + L.whh,
+                           (const float*)(ws + L.xproj) + (size_t)t * B * G, G,
+                           (const float*)(ws + L.c_all) + (size_t)t * B * H,
+                           training ? ws + L.gates + (size_t)t * B * G * es : nullptr,
+                           (float*)(ws + L.c_all) + (size_t)(t + 1) * B * H,
+                           ws + L.h_all + (size_t)(t + 1) * B * H * es, B, H, dt, st);
+      if (rc) return rc;
+    }
+  }
+  return CSN_OK;
+}
+
+static int backward_v1(const csnLstmDesc* d, const WsLayout& w, char* ws, const float* dy_last, const float* dy_tm,
+                       float* const* dw_ih, float* const* dw_hh, float* const* db_ih, float* const* db_hh, float* dx,
+                       csnStream_t stream) {
+  hipStream_t st = as_stream(stream);
+  const int B = d->B, T = d->T, H = d->H, dt = d->dtype;
+  const int64_t G = 4 * (int64_t)H, TB = (int64_t)T * B;
+  const size_t es = dtype_size(dt);
+  int rc;
+  for (int l = d->L - 1; l >= 0; --l) {
+    const LayerWs& L = w.layer[l];
+    const int64_t I = l == 0 ? d->I : H;
+    const bool top = (l == d->L - 1);
+    const float* dy_src = top ? dy_tm : (const float*)(ws + w.layer[l + 1].dx);
+    CSN_HIP_CHECK(hipMemsetAsync(ws + L.dc_carry, 0, (size_t)B * H * 4, st));
+    for (int t = T - 1; t >= 0; --t) {
+      const float* dy_t = dy_src ? dy_src + (size_t)t * B * H : ((top && t == T - 1) ? dy_last : nullptr);
+      const void* dg_next = (t == T - 1) ? nullptr : (const void*)(ws + L.dgates + (size_t)(t + 1) * B * G * es);
+      rc = launch_cell_bwd(dg_next, ws + L.whht, dy_t, H, ws + L.gates + (size_t)t * B * G * es,
+                           (const float*)(ws + L.c_all) + (size_t)(t + 1) * B * H,
+                           (const float*)(ws + L.c_all) + (size_t)t * B * H, (float*)(ws + L.dc_carry),
+                           ws + L.dgates + (size_t)t * B * G * es, B, H, dt, st);
+      if (rc) return rc;
+    }
+    const void* inp = l == 0 ? (const void*)(ws + w.x_c)
+                             : (const void*)(ws + w.layer[l - 1].h_all + (size_t)B * H * es);
+    if ((rc = csn_gemm_tn(ws + L.dgates, ws + L.h_all, dw_hh[l], G, H, TB, dt, ws + w.tn_scratch, stream))) return rc;
+    if ((rc = csn_gemm_tn(ws + L.dgates, inp, dw_ih[l], G, I, TB, dt, ws + w.tn_scratch, stream))) return rc;
+    if ((rc = launch_colsum(ws + L.dgates, TB, G, dt, db_ih[l], ws + w.colsum, st))) return rc;
+    CSN_HIP_CHECK(hipMemcpyAsync(db_hh[l], db_ih[l], (size_t)G * 4, hipMemcpyDeviceToDevice, st));
+    if (l > 0 || dx) {
+      if ((rc = csn_gemm_nt(ws + L.dgates, ws + L.wiht, nullptr, ws + L.dx, TB, I, G, dt, CSN_F32, 0, stream)))
+        return rc;
+      if (l == 0) {
+        tb_to_bt_kernel<<<grid_for(TB * I), 256, 0, st>>>((const float*)(ws + L.dx), dx, B, T, (int)I);
+        CSN_LAUNCH_CHECK();
+      }
+    }
+  }
+  return CSN_OK;
+}
+
+// =============================================================================================
+// il fast path (wavefront over layers, GEMMs on the side stream)
+// =============================================================================================
+static int forward_il(const csnLstmDesc* d, const WsLayout& w, char* ws, const float* x, int64_t xsb, int64_t xst,
+                      const float* const* w_ih, const float* const* w_hh, const float* const* b_ih,
+                      const float* const* b_hh, int training, csnStream_t stream) {
+  hipStream_t st = as_stream(stream);
+  SideCtx* sc;
+  int rc;
+  if ((rc = side_ctx(&sc))) return rc;
+  hipStream_t side = getenv("CSN_NO_SIDE_STREAM") ? st : sc->side;
+  const int B = d->B, T = d->T, H = d->H, NL = d->L;
+  const int64_t G = 4 * (int64_t)H, TB = (int64_t)T * B;
+  const size_t Bpad = ((size_t)B + 63) / 64 * 64;
+  const int Cz = chunk_steps(), lag = 2 * Cz;
+
+  if ((rc = launch_cast_strided(x, xsb, xst, B, T, d->I, ws + w.x_c, CSN_BF16, st))) return rc;
+  for (int l = 0; l < NL; ++l) {
+    const LayerWs& L = w.layer[l];
+    const int64_t I = l == 0 ? d->I : H;
+    if ((rc = launch_permute_rows_cast(w_ih[l], H, I, ws + L.wih, st))) return rc;
+    if ((rc = launch_blockify(w_hh[l], H, 1, G, H, 1, 0, H, ws + L.whh_blk, st))) return rc;
+    if ((rc = launch_bias_perm_sum(b_ih[l], b_hh[l], H, (float*)(ws + L.bias), st))) return rc;
+    if (training) {
+      if ((rc = launch_transpose_perm_cast(w_ih[l], H, I, ws + L.wiht, st))) return rc;
+      // W_hh^T [H rows = unit][k' = 4u'+g]: element (u, k') = W_hh[std_row(k')][u]
+      if ((rc = launch_blockify(w_hh[l], 1, H, H, G, 0, 1, H, ws + L.whht_blk, st))) return rc;
+    }
+    CSN_HIP_CHECK(hipMemsetAsync(ws + L.hblk[0], 0, Bpad * H * 2, st));
+    CSN_HIP_CHECK(hipMemsetAsync(ws + L.hblk[1], 0, Bpad * H * 2, st));
+    CSN_HIP_CHECK(hipMemsetAsync(ws + L.h_all, 0, (size_t)B * H * 2, st));
+    CSN_HIP_CHECK(hipMemsetAsync(ws + L.c_all, 0, (size_t)B * H * 4, st));
+  }
+  // layer 0 input projection for every step, main stream
+  if ((rc = csn_gemm_nt(ws + w.x_c, ws + w.layer[0].wih, (const float*)(ws + w.layer[0].bias), ws + w.layer[0].xproj,
+                        TB, G, d->I, CSN_BF16, CSN_F32, 0, stream)))
+    return rc;
+  if (NL > 1 && (rc = hand_off(sc, st, side))) return rc;   // side stream sees the prepared weights
+
+  const int nch = (T + Cz - 1) / Cz;
+  std::vector<hipEvent_t> xproj_ready((size_t)NL * nch, nullptr);
+  const int D = T + lag * (NL - 1);
+  for (int dg = 0; dg < D; ++dg) {
+    CellFwdArgs a{};
+    a.B = B;
+    a.H = H;
+    int np = 0;
+    for (int l = 0; l < NL; ++l) {
+      const int t = dg - lag * l;
+      if (t < 0 || t >= T) continue;
+      const LayerWs& L = w.layer[l];
+      if (l > 0 && t % Cz == 0) CSN_HIP_CHECK(hipStreamWaitEvent(st, xproj_ready[(size_t)l * nch + t / Cz], 0));
+      CellFwdProb& P = a.p[np++];
+      P.h_prev_blk = t == 0 ? nullptr : (const bf16_t*)(ws + L.hblk[t & 1]);
+      P.w_blk = (const bf16_t*)(ws + L.whh_blk);
+      P.xproj = (const float*)(ws + L.xproj) + (size_t)t * B * G;
+      P.c_prev = t == 0 ? nullptr : (const float*)(ws + L.c_all) + (size_t)t * B * H;
+      P.gates_out = training ? (bf16_t*)(ws + L.gates) + (size_t)t * B * G : nullptr;
+      P.c_out = (float*)(ws + L.c_all) + (size_t)(t + 1) * B * H;
+      P.h_out = (bf16_t*)(ws + L.h_all) + (size_t)(t + 1) * B * H;
+      P.h_out_blk = (bf16_t*)(ws + L.hblk[(t + 1) & 1]);
+    }
+    if (np == 0) continue;
+    if ((rc = launch_cell_fwd_il(a, np, st))) return rc;
+    // a layer that just finished a chunk feeds the next layer's input projection (side stream)
+    for (int l = 0; l + 1 < NL; ++l) {
+      const int t = dg - lag * l;
+      if (t < 0 || t >= T) continue;
+      if ((t + 1) % Cz != 0 && t != T - 1) continue;
+      const int c = t / Cz, t0 = c * Cz, nsteps = t - t0 + 1;
+      if ((rc = hand_off(sc, st, side))) return rc;
+      const LayerWs& Ln = w.layer[l + 1];
+      rc = csn_gemm_nt((const bf16_t*)(ws + w.layer[l].h_all) + (size_t)(t0 + 1) * B * H, ws + Ln.wih,
+                       (const float*)(ws + Ln.bias), (float*)(ws + Ln.xproj) + (size_t)t0 * B * G,
+                       (int64_t)nsteps * B, G, H, CSN_BF16, CSN_F32, 0, (csnStream_t)side);
+      if (rc) return rc;
+      hipEvent_t ev;
+      if ((rc = next_event(sc, &ev))) return rc;
+      CSN_HIP_CHECK(hipEventRecord(ev, side));
+      xproj_ready[(size_t)(l + 1) * nch + c] = ev;
+    }
+  }
+  return CSN_OK;
+}
+
+static int backward_il(const csnLstmDesc* d, const WsLayout& w, char* ws, const float* dy_last, const float* dy_tm,
+                       float* const* dw_ih, float* const* dw_hh, float* const* db_ih, float* const* db_hh, float* dx,
+                       csnStream_t stream) {
+  hipStream_t st = as_stream(stream);
+  SideCtx* sc;
+  int rc;
+  if ((rc = side_ctx(&sc))) return rc;
+  hipStream_t side = getenv("CSN_NO_SIDE_STREAM") ? st : sc->side;
+  const int B = d->B, T = d->T, H = d->H, NL = d->L;
+  const int64_t G = 4 * (int64_t)H, TB = (int64_t)T * B;
+  const size_t Bpad = ((size_t)B + 63) / 64 * 64;
+  const int Cz = chunk_steps(), lag = 2 * Cz;
+  const int nch = (T + Cz - 1) / Cz;
+
+  for (int l = 0; l < NL; ++l) {
+    const LayerWs& L = w.layer[l];
+    CSN_HIP_CHECK(hipMemsetAsync(ws + L.dc_carry, 0, (size_t)B * H * 4, st));
+    CSN_HIP_CHECK(hipMemsetAsync(ws + L.dgblk[0], 0, Bpad * G * 2, st));
+    CSN_HIP_CHECK(hipMemsetAsync(ws + L.dgblk[1], 0, Bpad * G * 2, st));
+  }
+  if ((rc = hand_off(sc, st, side))) return rc;
+
+  // weight / bias gradients of one layer, on the side stream (after its recurrence is complete)
+  auto weight_grads = [&](int l) -> int {
+    const LayerWs& L = w.layer[l];
+    const int64_t I = l == 0 ? d->I : H;
+    const void* inp = l == 0 ? (const void*)(ws + w.x_c)
+                             : (const void*)((const bf16_t*)(ws + w.layer[l - 1].h_all) + (size_t)B * H);
+    float* slabs = (float*)(ws + w.tn_scratch);
+    int S = 1, r;
+    if ((r = launch_gemm_tn_slabs(ws + L.dgates, ws + L.h_all, slabs, G, H, TB, CSN_BF16, side, &S))) return r;
+    if ((r = launch_reduce_slabs_unperm(slabs, G * H, S, H, H, dw_hh[l], side))) return r;
+    if ((r = launch_gemm_tn_slabs(ws + L.dgates, inp, slabs, G, I, TB, CSN_BF16, side, &S))) return r;
+    if ((r = launch_reduce_slabs_unperm(slabs, G * I, S, H, I, dw_ih[l], side))) return r;
+    if ((r = launch_colsum_partial(ws + L.dgates, TB, G, CSN_BF16, ws + w.colsum, side))) return r;
+    if ((r = launch_reduce_slabs_unperm((const float*)(ws + w.colsum), G, colsum_chunks(), H, 1, db_ih[l], side)))
+      return r;
+    CSN_HIP_CHECK(hipMemcpyAsync(db_hh[l], db_ih[l], (size_t)G * 4, hipMemcpyDeviceToDevice, side));
+    return CSN_OK;
+  };
+
+  std::vector<hipEvent_t> dx_ready((size_t)NL * nch, nullptr);
+  const int D = T + lag * (NL - 1);
+  for (int dg = 0; dg < D; ++dg) {
+    CellBwdArgs a{};
+    a.B = B;
+    a.H = H;
+    int np = 0;
+    for (int l = NL - 1; l >= 0; --l) {
+      const int r = dg - lag * (NL - 1 - l);      // reverse step index of layer l on this diagonal
+      if (r < 0 || r >= T) continue;
+      const int t = T - 1 - r;
+      const LayerWs& L = w.layer[l];
+      const bool top = (l == NL - 1);
+      if (!top && r % Cz == 0) CSN_HIP_CHECK(hipStreamWaitEvent(st, dx_ready[(size_t)(l + 1) * nch + r / Cz], 0));
+      CellBwdProb& P = a.p[np++];
+      P.dg_next_blk = (t == T - 1) ? nullptr : (const bf16_t*)(ws + L.dgblk[(t + 1) & 1]);
+      P.wt_blk = (const bf16_t*)(ws + L.whht_blk);
+      if (top) {
+        P.dy = dy_tm ? dy_tm + (size_t)t * B * H : (t == T - 1 ? dy_last : nullptr);
+      } else {
+        P.dy = (const float*)(ws + w.layer[l + 1].dx) + (size_t)t * B * H;
+      }
+      P.dy_ld = H;
+      P.gates = (const bf16_t*)(ws + L.gates) + (size_t)t * B * G;
+      P.c = (const float*)(ws + L.c_all) + (size_t)(t + 1) * B * H;
+      P.c_prev = t == 0 ? nullptr : (const float*)(ws + L.c_all) + (size_t)t * B * H;
+      P.dc_carry = (float*)(ws + L.dc_carry);
+      P.dg_out = (bf16_t*)(ws + L.dgates) + (size_t)t * B * G;
+      P.dg_out_blk = (bf16_t*)(ws + L.dgblk[t & 1]);
+    }
+    if (np == 0) continue;
+    if ((rc = launch_cell_bwd_il(a, np, st))) return rc;
+    for (int l = NL - 1; l >= 0; --l) {
+      const int r = dg - lag * (NL - 1 - l);
+      if (r < 0 || r >= T) continue;
+      const bool chunk_end = ((r + 1) % Cz == 0) || r == T - 1;
+      if (!chunk_end) continue;
+      const LayerWs& L = w.layer[l];
+      const int64_t I = l == 0 ? d->I : H;
+      const int cr = r / Cz;
+      const int t_lo = T - 1 - r, t_hi = T - 1 - cr * Cz;       // steps covered by this (reverse) chunk
+      const bool last = (r == T - 1);
+      if (l > 0 || last) {
+        if ((rc = hand_off(sc, st, side))) return rc;
+      }
+      if (l > 0) {
+        // dx_l[chunk] = dgates_l[chunk] (interleaved K) * W_ih;  Bt = W_ih^T [I, 4H']
+        rc = csn_gemm_nt((const bf16_t*)(ws + L.dgates) + (size_t)t_lo * B * G, ws + L.wiht, nullptr,
+                         (float*)(ws + L.dx) + (size_t)t_lo * B * I, (int64_t)(t_hi - t_lo + 1) * B, I, G, CSN_BF16,
+                         CSN_F32, 0, (csnStream_t)side);
+        if (rc) return rc;
+        hipEvent_t ev;
+        if ((rc = next_event(sc, &ev))) return rc;
+        CSN_HIP_CHECK(hipEventRecord(ev, side));
+        dx_ready[(size_t)l * nch + cr] = ev;
+      } else if (last && dx != nullptr) {
+        rc = csn_gemm_nt(ws + L.dgates, ws + L.wiht, nullptr, ws + L.dx, TB, I, G, CSN_BF16, CSN_F32, 0,
+                         (csnStream_t)side);
+        if (rc) return rc;
+        tb_to_bt_kernel<<<grid_for(TB * I), 256, 0, side>>>((const float*)(ws + L.dx), dx, B, T, (int)I);
+        CSN_LAUNCH_CHECK();
+      }
+      if (last && (rc = weight_grads(l))) return rc;
+    }
+  }
+  return hand_off(sc, side, st);   // the caller's stream resumes after all side-stream work
+}
+
+// =============================================================================================
 extern "C" int csn_lstm_forward(const csnLstmDesc* d, const float* x, int64_t x_stride_b, int64_t x_stride_t,
                                 const float* const* w_ih, const float* const* w_hh, const float* const* b_ih,
                                 const float* const* b_hh, void* workspace, int training, float* y_last, float* y_all,
@@ -147,57 +489,28 @@ extern "C" int csn_lstm_forward(const csnLstmDesc* d, const float* x, int64_t x_
   CSN_REQUIRE(x && w_ih && w_hh && b_ih && b_hh && workspace, "csn_lstm_forward: null pointer");
   CSN_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 255) == 0, "csn_lstm_forward: workspace must be 256-B aligned");
   CSN_REQUIRE(y_last || y_all, "csn_lstm_forward: no output requested");
+  for (int l = 0; l < d->L; ++l)
+    CSN_REQUIRE(w_ih[l] && w_hh[l] && b_ih[l] && b_hh[l], "csn_lstm_forward: null parameter pointer, layer %d", l);
   hipStream_t st = as_stream(stream);
   const WsLayout w = make_layout(*d, training);
   char* ws = (char*)workspace;
   const int B = d->B, T = d->T, H = d->H, dt = d->dtype;
-  const int64_t G = 4 * (int64_t)H, TB = (int64_t)T * B;
   const size_t es = dtype_size(dt);
   int rc;
-
-  // time-major copy of the input in the compute dtype: x_c[t][b][i]
-  if ((rc = launch_cast_strided(x, x_stride_b, x_stride_t, B, T, d->I, ws + w.x_c, dt, st))) return rc;
-
-  for (int l = 0; l < d->L; ++l) {
-    const LayerWs& L = w.layer[l];
-    const int64_t I = l == 0 ? d->I : H;
-    CSN_REQUIRE(w_ih[l] && w_hh[l] && b_ih[l] && b_hh[l], "csn_lstm_forward: null parameter pointer, layer %d", l);
-    // compute-dtype copies of the weights (+ transposes for the backward pass)
-    if ((rc = launch_cast(w_ih[l], ws + L.wih, G * I, dt, st))) return rc;
-    if ((rc = launch_cast(w_hh[l], ws + L.whh, G * H, dt, st))) return rc;
-    if (training) {
-      if ((rc = launch_transpose_cast(w_hh[l], G, H, ws + L.whht, dt, st))) return rc;
-      if ((rc = launch_transpose_cast(w_ih[l], G, I, ws + L.wiht, dt, st))) return rc;
-    }
-    if ((rc = launch_add_vec(b_ih[l], b_hh[l], (float*)(ws + L.bias), G, st))) return rc;
-
-    // xproj[T*B, 4H] = inp[T*B, I] * W_ih^T + bias
-    const void* inp = l == 0 ? (const void*)(ws + w.x_c)
-                             : (const void*)(ws + w.layer[l - 1].h_all + (size_t)B * H * es);
-    if ((rc = csn_gemm_nt(inp, ws + L.wih, (const float*)(ws + L.bias), ws + L.xproj, TB, G, I, dt, CSN_F32, 0,
-                          stream)))
-      return rc;
-
-    CSN_HIP_CHECK(hipMemsetAsync(ws + L.h_all, 0, (size_t)B * H * es, st));
-    CSN_HIP_CHECK(hipMemsetAsync(ws + L.c_all, 0, (size_t)B * H * 4, st));
-    for (int t = 0; t < T; ++t) {
-      const char* h_prev = ws + L.h_all + (size_t)t * B * H * es;
-      const float* c_prev = (const float*)(ws + L.c_all) + (size_t)t * B * H;
-      rc = launch_cell_fwd(h_prev, ws + L.whh, (const float*)(ws + L.xproj) + (size_t)t * B * G, G, c_prev,
-                           training ? ws + L.gates + (size_t)t * B * G * es : nullptr,
-                           (float*)(ws + L.c_all) + (size_t)(t + 1) * B * H,
-                           ws + L.h_all + (size_t)(t + 1) * B * H * es, B, H, dt, st);
-      if (rc) return rc;
-    }
-  }
+  if (w.il)
+    rc = forward_il(d, w, ws, x, x_stride_b, x_stride_t, w_ih, w_hh, b_ih, b_hh, training, stream);
+  else
+    rc = forward_v1(d, w, ws, x, x_stride_b, x_stride_t, w_ih, w_hh, b_ih, b_hh, training, stream);
+  if (rc) return rc;
   const LayerWs& top = w.layer[d->L - 1];
   if (y_last)
     if ((rc = launch_upcast(ws + top.h_all + (size_t)T * B * H * es, dt, y_last, (int64_t)B * H, st))) return rc;
   if (y_all) {
+    const int64_t n = (int64_t)T * B * H;
     if (dt == CSN_BF16)
-      gather_y_all_kernel<bf16_t><<<grid_for(TB * H), 256, 0, st>>>((const bf16_t*)(ws + top.h_all), y_all, B, T, H);
+      gather_y_all_kernel<bf16_t><<<grid_for(n), 256, 0, st>>>((const bf16_t*)(ws + top.h_all), y_all, B, T, H);
     else
-      gather_y_all_kernel<float><<<grid_for(TB * H), 256, 0, st>>>((const float*)(ws + top.h_all), y_all, B, T, H);
+      gather_y_all_kernel<float><<<grid_for(n), 256, 0, st>>>((const float*)(ws + top.h_all), y_all, B, T, H);
     CSN_LAUNCH_CHECK();
   }
   return CSN_OK;
@@ -209,13 +522,13 @@ extern "C" int csn_lstm_backward(const csnLstmDesc* d, const float* dy_last, con
   if (int rc = check_desc("csn_lstm_backward", d)) return rc;
   CSN_REQUIRE(workspace && dw_ih && dw_hh && db_ih && db_hh, "csn_lstm_backward: null pointer");
   CSN_REQUIRE(dy_last || dy_all, "csn_lstm_backward: no incoming gradient");
+  for (int l = 0; l < d->L; ++l)
+    CSN_REQUIRE(dw_ih[l] && dw_hh[l] && db_ih[l] && db_hh[l], "csn_lstm_backward: null gradient pointer, layer %d", l);
   hipStream_t st = as_stream(stream);
   const WsLayout w = make_layout(*d, 1);
   char* ws = (char*)workspace;
-  const int B = d->B, T = d->T, H = d->H, dt = d->dtype;
-  const int64_t G = 4 * (int64_t)H, TB = (int64_t)T * B;
-  const size_t es = dtype_size(dt);
-  int rc;
+  const int B = d->B, T = d->T, H = d->H;
+  const int64_t TB = (int64_t)T * B;
 
   // gradient w.r.t. the top layer's outputs, time-major.  With only dy_last, no buffer is needed.
   const float* dy_tm = nullptr;
@@ -229,41 +542,6 @@ extern "C" int csn_lstm_backward(const csnLstmDesc* d, const float* dy_last, con
     }
     dy_tm = buf;
   }
-
-  for (int l = d->L - 1; l >= 0; --l) {
-    const LayerWs& L = w.layer[l];
-    const int64_t I = l == 0 ? d->I : H;
-    CSN_REQUIRE(dw_ih[l] && dw_hh[l] && db_ih[l] && db_hh[l], "csn_lstm_backward: null gradient pointer, layer %d", l);
-    const bool top = (l == d->L - 1);
-    const float* dy_src = top ? dy_tm : (const float*)(ws + w.dx_buf[l & 1]);   // [T,B,H] or null
-    CSN_HIP_CHECK(hipMemsetAsync(ws + w.dc_carry, 0, (size_t)B * H * 4, st));
-    for (int t = T - 1; t >= 0; --t) {
-      const float* dy_t = dy_src ? dy_src + (size_t)t * B * H : ((top && t == T - 1) ? dy_last : nullptr);
-      const void* dg_next = (t == T - 1) ? nullptr : (const void*)(ws + L.dgates + (size_t)(t + 1) * B * G * es);
-      rc = launch_cell_bwd(dg_next, ws + L.whht, dy_t, H, ws + L.gates + (size_t)t * B * G * es,
-                           (const float*)(ws + L.c_all) + (size_t)(t + 1) * B * H,
-                           (const float*)(ws + L.c_all) + (size_t)t * B * H, (float*)(ws + w.dc_carry),
-                           ws + L.dgates + (size_t)t * B * G * es, B, H, dt, st);
-      if (rc) return rc;
-    }
-    // weight gradients: contraction over all T*B rows
-    const void* inp = l == 0 ? (const void*)(ws + w.x_c)
-                             : (const void*)(ws + w.layer[l - 1].h_all + (size_t)B * H * es);
-    if ((rc = csn_gemm_tn(ws + L.dgates, ws + L.h_all, dw_hh[l], G, H, TB, dt, ws + w.tn_scratch, stream))) return rc;
-    if ((rc = csn_gemm_tn(ws + L.dgates, inp, dw_ih[l], G, I, TB, dt, ws + w.tn_scratch, stream))) return rc;
-    if ((rc = launch_colsum(ws + L.dgates, TB, G, dt, db_ih[l], ws + w.colsum, st))) return rc;
-    CSN_HIP_CHECK(hipMemcpyAsync(db_hh[l], db_ih[l], (size_t)G * 4, hipMemcpyDeviceToDevice, st));
-    // gradient flowing to the layer below: dx[T*B, I] = dgates[T*B, 4H] * W_ih   (Bt = W_ih^T [I,4H])
-    if (l > 0) {
-      if ((rc = csn_gemm_nt(ws + L.dgates, ws + L.wiht, nullptr, ws + w.dx_buf[(l - 1) & 1], TB, I, G, dt, CSN_F32, 0,
-                            stream)))
-        return rc;
-    } else if (dx) {
-      float* tmp = (float*)(ws + w.dx_buf[1]);   // time-major [T,B,I], then re-laid batch-first for the caller
-      if ((rc = csn_gemm_nt(ws + L.dgates, ws + L.wiht, nullptr, tmp, TB, I, G, dt, CSN_F32, 0, stream))) return rc;
-      tb_to_bt_kernel<<<grid_for(TB * I), 256, 0, st>>>(tmp, dx, B, T, (int)I);
-      CSN_LAUNCH_CHECK();
-    }
-  }
-  return CSN_OK;
+  if (w.il) return backward_il(d, w, ws, dy_last, dy_tm, dw_ih, dw_hh, db_ih, db_hh, dx, stream);
+  return backward_v1(d, w, ws, dy_last, dy_tm, dw_ih, dw_hh, db_ih, db_hh, dx, stream);
 }

@@ -19,6 +19,7 @@
 // bf16 variant: v_mfma_f32_16x16x32_bf16, f32 accumulate, f32 cell state, bf16 h / gates.
 // f32 variant : v_mfma_f32_16x16x4_f32 (exact f32 fma chain) -- the parity path.
 #include "csn_common.h"
+#include "lstm_cell_common.h"
 
 namespace csn {
 
@@ -46,27 +47,6 @@ template <> struct Frag<float> {
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[jj], b[jj], acc, 0, 0, 0);
     return acc;
-  }
-};
-
-template <typename T> struct Vec4;
-template <> struct Vec4<float> {
-  static __device__ __forceinline__ void store(float* p, const float (&v)[4]) {
-    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
-  }
-  static __device__ __forceinline__ void load(const float* p, float (&v)[4]) {
-    const float4 q = *reinterpret_cast<const float4*>(p);
-    v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
-  }
-};
-template <> struct Vec4<bf16_t> {
-  static __device__ __forceinline__ void store(bf16_t* p, const float (&v)[4]) {
-    bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
-    *reinterpret_cast<bf16x4*>(p) = o;
-  }
-  static __device__ __forceinline__ void load(const bf16_t* p, float (&v)[4]) {
-    const bf16x4 q = *reinterpret_cast<const bf16x4*>(p);
-    v[0] = (float)q[0]; v[1] = (float)q[1]; v[2] = (float)q[2]; v[3] = (float)q[3];
   }
 };
 
@@ -202,6 +182,7 @@ lstm_cell_bwd_kernel(const T* __restrict__ dg_next, const T* __restrict__ w_hh_t
   Vec4<T>::store(op + 3 * (int64_t)H, dao);
   Vec4<float>::store(dc_carry + (int64_t)mrow * H + ub, dcarry);
 }
+
 
 int launch_cell_fwd(const void* h_prev, const void* w_hh, const float* xproj, int64_t xproj_ld, const float* c_prev,
                     void* gates_out, float* c_out, void* h_out, int B, int H, int dtype, hipStream_t st) {

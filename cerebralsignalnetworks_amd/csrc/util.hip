@@ -166,13 +166,20 @@ __global__ void colsum_partial_kernel(const T* __restrict__ X, int64_t R, int64_
   partial[(int64_t)blockIdx.y * N + col] = acc;
 }
 
-int launch_colsum(const void* X, int64_t R, int64_t N, int dtype, float* out, void* scratch, hipStream_t st) {
+int colsum_chunks() { return kColsumChunks; }
+
+int launch_colsum_partial(const void* X, int64_t R, int64_t N, int dtype, void* scratch, hipStream_t st) {
   dim3 grid((unsigned)((N + 255) / 256), kColsumChunks);
   float* partial = (float*)scratch;
   if (dtype == CSN_BF16) colsum_partial_kernel<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)X, R, N, partial);
   else colsum_partial_kernel<float><<<grid, 256, 0, st>>>((const float*)X, R, N, partial);
   CSN_LAUNCH_CHECK();
-  return launch_reduce_slabs(partial, N, kColsumChunks, out, N, 0, st);
+  return CSN_OK;
+}
+
+int launch_colsum(const void* X, int64_t R, int64_t N, int dtype, float* out, void* scratch, hipStream_t st) {
+  if (int rc = launch_colsum_partial(X, R, N, dtype, scratch, st)) return rc;
+  return launch_reduce_slabs((const float*)scratch, N, kColsumChunks, out, N, 0, st);
 }
 
 }  // namespace csn

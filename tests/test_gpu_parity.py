@@ -381,3 +381,63 @@ def test_end_to_end_step_loss_within_1e4(cuda):
     gref = grads["lstm.weight_hh_l1"]
     big = np.abs(gref) > 1e-3 * np.abs(gref).max()
     assert (np.sign(step[big]) == -np.sign(gref[big])).mean() > 0.999
+
+
+# ----------------------------------------------------------------------------------------------
+# bf16 fast path ("il": fragment-major, gate-interleaved, layer wavefront, side-stream GEMMs)
+# ----------------------------------------------------------------------------------------------
+def _run_lstm(p, x, dy_all, dy_last, C, H, L, dtype, cuda, env=None):
+    env = env or {}
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        m = _model_from_params(p, C, H, L, 8, None, dtype, cuda)
+        xt = dev_t(x, cuda).requires_grad_(True)
+        y_all, y_last = m.lstm(xt, want_all=True)
+        loss = (y_all * dev_t(dy_all, cuda)).sum() + (y_last * dev_t(dy_last, cuda)).sum()
+        loss.backward()
+        torch.cuda.synchronize()
+        out = dict(y_all=y_all.detach().cpu().numpy(), dx=xt.grad.cpu().numpy())
+        for n, q in m.lstm.named_parameters():
+            out[n] = q.grad.cpu().numpy()
+        return out
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def _rel(a, b):
+    return np.linalg.norm(np.asarray(a, np.float64) - b) / max(1e-12, np.linalg.norm(b))
+
+
+@pytest.mark.parametrize("B,T,C,H,L,chunk", [(70, 75, 24, 128, 2, "32"), (33, 40, 16, 128, 3, "8"),
+                                             (64, 20, 32, 256, 1, "32"), (5, 9, 8, 384, 2, "4")])
+def test_fast_path_matches_oracle_and_v1(cuda, B, T, C, H, L, chunk):
+    rng = np.random.default_rng(B * T + H)
+    p = lstm.init_params(C, H, L, 8, None, seed=5)
+    lp = {k[len("lstm."):]: v for k, v in p.items() if k.startswith("lstm.")}
+    x = rng.standard_normal((B, T, C)).astype(np.float32)
+    dy_all = (rng.standard_normal((B, T, H)) * 0.1).astype(np.float32)
+    dy_last = rng.standard_normal((B, H)).astype(np.float32)
+    y, saved = lstm.lstm_forward(x, lp, L, return_saved=True)
+    dy = dy_all.astype(np.float64).copy()
+    dy[:, -1] += dy_last
+    dx_ref, g_ref = lstm.lstm_backward(dy, lp, saved, L)
+
+    fast = _run_lstm(p, x, dy_all, dy_last, C, H, L, torch.bfloat16, cuda, {"CSN_LSTM_CHUNK": chunk})
+    slow = _run_lstm(p, x, dy_all, dy_last, C, H, L, torch.bfloat16, cuda, {"CSN_CELL_V1": "1"})
+    serial = _run_lstm(p, x, dy_all, dy_last, C, H, L, torch.bfloat16, cuda,
+                       {"CSN_LSTM_CHUNK": chunk, "CSN_NO_SIDE_STREAM": "1"})
+    # the wavefront with side-stream GEMMs computes exactly what the single-stream schedule computes
+    for k in fast:
+        np.testing.assert_array_equal(fast[k], serial[k], err_msg=k)
+    assert np.abs(fast["y_all"] - y).max() < 3e-2
+    assert _rel(fast["dx"], dx_ref) < 4e-2
+    for k, v in g_ref.items():
+        assert _rel(fast[k], v) < 4e-2, (k, _rel(fast[k], v))
+        # same bf16 arithmetic, different layouts / activations: much closer to each other than to f64
+        assert _rel(fast[k], slow[k]) < 2e-2, (k, _rel(fast[k], slow[k]))
+    assert np.abs(fast["y_all"] - slow["y_all"]).max() < 2e-2
