@@ -154,16 +154,50 @@ int launch_reduce_slabs(const float* slabs, int64_t stride, int S, float* out, i
 static const int kColsumChunks = 128;
 size_t colsum_scratch_bytes(int64_t N) { return (size_t)kColsumChunks * (size_t)N * sizeof(float); }
 
+// 256 threads = 32 column groups (8 columns = one 16-byte load for bf16) x 8 row lanes; a block
+// covers 256 columns of one row chunk, streams its rows with 16-byte loads, then folds the 8 row
+// lanes through LDS in a fixed order.
 template <typename T>
-__global__ void colsum_partial_kernel(const T* __restrict__ X, int64_t R, int64_t N, float* __restrict__ partial) {
-  const int64_t col = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (col >= N) return;
+__global__ void __launch_bounds__(256)
+colsum_partial_kernel(const T* __restrict__ X, int64_t R, int64_t N, float* __restrict__ partial) {
+  __shared__ float sh[8][256 + 1];
+  const int cg = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int64_t col0 = (int64_t)blockIdx.x * 256 + cg * 8;
   const int64_t rows_per = (R + gridDim.y - 1) / gridDim.y;
   const int64_t r0 = (int64_t)blockIdx.y * rows_per;
   const int64_t r1 = (r0 + rows_per < R) ? r0 + rows_per : R;
-  float acc = 0.0f;
-  for (int64_t r = r0; r < r1; ++r) acc += to_f32(X[r * N + col]);
-  partial[(int64_t)blockIdx.y * N + col] = acc;
+  float acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = 0.0f;
+  if (col0 + 7 < N && (N % 8 == 0)) {
+    for (int64_t r = r0 + rl; r < r1; r += 8) {
+      if constexpr (sizeof(T) == 2) {
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(X + r * N + col0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += (float)v[j];
+      } else {
+        const float4 a = *reinterpret_cast<const float4*>(X + r * N + col0);
+        const float4 b = *reinterpret_cast<const float4*>(X + r * N + col0 + 4);
+        acc[0] += a.x; acc[1] += a.y; acc[2] += a.z; acc[3] += a.w;
+        acc[4] += b.x; acc[5] += b.y; acc[6] += b.z; acc[7] += b.w;
+      }
+    }
+  } else {
+    for (int64_t r = r0 + rl; r < r1; r += 8)
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (col0 + j < N) acc[j] += to_f32(X[r * N + col0 + j]);
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) sh[rl][cg * 8 + j] = acc[j];
+  __syncthreads();
+  const int64_t col = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (col < N) {
+    float t = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += sh[k][threadIdx.x];
+    partial[(int64_t)blockIdx.y * N + col] = t;
+  }
 }
 
 int colsum_chunks() { return kColsumChunks; }
