@@ -441,3 +441,68 @@ def test_fast_path_matches_oracle_and_v1(cuda, B, T, C, H, L, chunk):
         # same bf16 arithmetic, different layouts / activations: much closer to each other than to f64
         assert _rel(fast[k], slow[k]) < 2e-2, (k, _rel(fast[k], slow[k]))
     assert np.abs(fast["y_all"] - slow["y_all"]).max() < 2e-2
+
+
+# ----------------------------------------------------------------------------------------------
+# CLI drop-ins (BASELINE.json configs[0] shape: 256 synthetic segments, batch 16, 1 epoch)
+# ----------------------------------------------------------------------------------------------
+def test_cli_train_then_eval_cfg1(cuda, tmp_path):
+    import LstmDistillFromDinoV2Train as train
+    import LstmDistillFromDinoV2Eval as evaluate_cli
+    args = ["--synthetic", "256", "--batch_size", "16", "--num_epochs", "1", "--log_dir", str(tmp_path),
+            "--hidden_size", "128", "--lstm_layers", "2", "--loss", "cosine", "--dtype", "f32"]
+    hist = train.main(args)
+    assert len(hist) == 1 and np.isfinite(hist[0]) and 0.5 < hist[0] < 1.5      # cosine loss vs random targets ~ 1
+    ckpt = os.path.join(str(tmp_path), "lstm_dinov2_best_loss.pth")
+    sd = torch.load(ckpt, weights_only=True)
+    assert "lstm.weight_hh_l1" in sd and "fc.weight" in sd
+    r = evaluate_cli.main(args + ["--custom_model_weights", ckpt, "--topK", "5"])
+    assert 0.0 <= r["Recall_Total"] <= 100.0 and r["I"].shape == (51, 5)
+    for suffix in (".pth", ".txt", "_.csv"):
+        assert os.path.exists(os.path.join(str(tmp_path), f"Theperils_sub_1_Scores{suffix}"))
+    # first optimisation step of the same configuration against the oracle (distill loss within 1e-4)
+    from cerebralsignalnetworks_amd.dataset import EEGDataset
+    from cerebralsignalnetworks_amd.trainer import DistillTrainer, shard_indices
+    torch.manual_seed(43)
+    ds = EEGDataset(synthetic=256, time_low=0, time_high=500, seed=43, device=cuda)
+    m = Model(input_size=128, lstm_size=128, lstm_layers=2, output_size=384, include_top=False,
+              compute_dtype=torch.float32).to(cuda)
+    p = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
+    filt = EEGFilters(1000, order=3)
+    tr = DistillTrainer(m, filt.sos, loss="cosine")
+    perm = torch.randperm(256, generator=torch.Generator().manual_seed(43))[:205]
+    b = perm[shard_indices(205, 0, 43, 0, 1)][:16].to(cuda)
+    loss = tr.train_step(ds.eeg_all[b], ds.features_all[b])
+    x = ds.eeg_all[b].cpu().numpy()
+    feat = lstm.model_forward(eeg_filter.eeg_bandpass_znorm(x, filt.sos), p, 2)
+    assert abs(loss.item() - losses.cosine_similarity_loss(feat, ds.features_all[b].cpu().numpy())) < 1e-4
+
+
+def test_featdist_and_kd_losses_train_on_gpu(cuda):
+    """The reference's active losses (FeatureDistributionLoss, loss_fn_kd) through the HIP model."""
+    from cerebralsignalnetworks_amd.trainer import DistillTrainer
+    from cerebralsignalnetworks_amd.losses import FeatureDistributionLoss, loss_fn_kd
+    rng = np.random.default_rng(2)
+    B, C, T, H, D = 8, 16, 40, 64, 24
+    x = rng.standard_normal((B, C, T)).astype(np.float32)
+    tgt = rng.standard_normal((B, D)).astype(np.float32)
+    lab = rng.integers(0, 40, B)
+    m = Model(input_size=C, lstm_size=H, lstm_layers=1, output_size=D, include_top=True,
+              compute_dtype=torch.float32).to(cuda)
+    p = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
+    tr = DistillTrainer(m, None, loss="featdist", nepochs=100)
+    loss = tr.train_step(dev_t(x, cuda), dev_t(tgt, cuda), dev_t(lab, cuda), epoch=25)
+    (feat, cls) = lstm.model_forward(eeg_filter.eeg_bandpass_znorm(x, np.zeros((0, 6))), p, 1, include_top=True)
+    want = losses.feature_distribution_loss(feat, tgt, losses.teacher_temp_schedule(100)[25], lab, cls)
+    assert abs(loss.item() - want) < 1e-4
+
+    class KD:
+        alpha, temperature = 0.5, 4.0
+    m2 = Model(input_size=C, lstm_size=H, lstm_layers=1, output_size=40, include_top=False,
+               compute_dtype=torch.float32).to(cuda)
+    p2 = {k: v.detach().cpu().numpy() for k, v in m2.state_dict().items()}
+    teacher = rng.standard_normal((B, 40)).astype(np.float32)
+    tr2 = DistillTrainer(m2, None, loss="kd", kd_params=KD)
+    loss2 = tr2.train_step(dev_t(x, cuda), dev_t(teacher, cuda), dev_t(lab, cuda))
+    feat2 = lstm.model_forward(eeg_filter.eeg_bandpass_znorm(x, np.zeros((0, 6))), p2, 1)
+    assert abs(loss2.item() - losses.loss_fn_kd(feat2, lab, teacher, 0.5, 4.0)) < 1e-4

@@ -1,0 +1,127 @@
+"""CPU: host-side logic -- CLI surface, dataset tuple contract, DistributedSampler-style sharding,
+flat-gradient all-reduce over a 2-process gloo group (the N>1 path of the trainer)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_cli_flags_match_reference_surface():
+    import LstmDistillFromDinoV2Train as train
+    # flags of /root/reference/LstmDistillFromDinoV2Train.py:151-225
+    ref = {"learning_rate": 0.001, "num_epochs": 100, "batch_size": 16, "log_dir": './logs/DinoV2LstmDistillv2sdsad/',
+           "gallery_subject": 1, "query_subject": 1, "images_root": "./data/images/imageNet_images",
+           "eeg_dataset_split": "./data/eeg/block_splits_by_image_all.pth", "mode": "train",
+           "custom_model_weights": "", "search_gallery": "train", "query_gallery": "test", "topK": 5,
+           "gallery_tranformation_type": "eeg2eeg", "query_tranformation_type": "eeg2eeg", "seed": 43,
+           "num_workers": 4, "dist_url": "env://", "local_rank": 0}
+    flags, unknown = train.build_parser().parse_known_args(["--not_a_flag", "3"])      # parse_known_args, :231
+    assert unknown == ["--not_a_flag", "3"]
+    for k, v in ref.items():
+        assert getattr(flags, k) == v, k
+    assert "eeg_dataset" in vars(flags) and "hyperprams" in vars(flags)
+    import ast
+    assert ast.literal_eval(flags.hyperprams)["temperature"] == 2
+
+
+def test_dataset_tuple_contract_and_label_bug_switch():
+    from cerebralsignalnetworks_amd.dataset import EEGDataset
+    ds = EEGDataset(synthetic=12, time_low=20, time_high=480, device=torch.device("cpu"), feature_dim=8)
+    eeg, label, image, i, feats = ds[3]
+    assert eeg.shape == (460, 128) and eeg.dtype == torch.float32          # [T,C], window 20:480
+    assert set(label) == {"ClassId", "ClassName", "imagenetClassId"} and i == 3 and feats.shape == (8,)
+    assert ds.class_str_to_id[ds.class_id_to_str[label["ClassId"]]] == label["ClassId"]
+    assert ds.getLabelbyIndex(3) == label and len(ds) == 12
+    np.testing.assert_array_equal(eeg.numpy(), ds.eeg_all[3].t().numpy())
+
+    class Identity(torch.nn.Module):
+        def forward(self, x):
+            return x.mean(dim=1)
+    loader = [([ds[j][0] for j in (5, 7)], None, None, torch.tensor([5, 7]), None)]
+    loader = [(torch.stack(loader[0][0]), None, None, loader[0][3], None)]
+    f, lab = ds.transformEEGDataLSTMByList(Identity(), loader)
+    assert [l["ClassId"] for l in lab] == [ds.getLabelbyIndex(5)["ClassId"], ds.getLabelbyIndex(7)["ClassId"]]
+    ds.compat_label_bug = True                                            # reference quirk: batch-local index
+    f, lab = ds.transformEEGDataLSTMByList(Identity(), loader)
+    assert [l["ClassId"] for l in lab] == [ds.getLabelbyIndex(0)["ClassId"], ds.getLabelbyIndex(1)["ClassId"]]
+
+
+def test_on_disk_format_round_trip(tmp_path):
+    """ConvertToPth.py:170-201 layout: {"dataset":[{eeg[C,T],image,label,subject}], "labels", "images", ...}."""
+    from cerebralsignalnetworks_amd.dataset import EEGDataset
+    g = torch.Generator().manual_seed(0)
+    items = [{"eeg": torch.randn(6, 50, generator=g), "image": k % 3, "label": k % 2, "subject": 1} for k in range(5)]
+    blob = {"dataset": items, "labels": ["n01", "n02"], "images": ["n01_a", "n02_b", "n01_c"],
+            "means": torch.zeros(6), "stddevs": torch.ones(6)}
+    path = tmp_path / "eeg.pth"
+    torch.save(blob, path)
+    ds = EEGDataset(eeg_signals_path=str(path), imagesRoot=str(tmp_path), time_low=5, time_high=45,
+                    device=torch.device("cpu"))
+    assert ds.eeg_all.shape == (5, 6, 40)
+    eeg, label, _, _, _ = ds[4]
+    np.testing.assert_array_equal(eeg.numpy(), items[4]["eeg"].t()[5:45].numpy())
+    assert label["ClassId"] == blob["labels"].index(blob["images"][items[4]["image"]].split("_")[0])
+
+
+def test_shard_indices_follow_distributed_sampler():
+    from torch.utils.data.distributed import DistributedSampler
+    from cerebralsignalnetworks_amd.trainer import shard_indices
+    n, world = 103, 4
+    seen = []
+    for r in range(world):
+        mine = shard_indices(n, epoch=3, seed=43, rank=r, world=world).tolist()
+        ref = list(DistributedSampler(range(n), num_replicas=world, rank=r, shuffle=True, seed=43))
+        # DistributedSampler needs set_epoch; emulate
+        s = DistributedSampler(range(n), num_replicas=world, rank=r, shuffle=True, seed=43)
+        s.set_epoch(3)
+        assert mine == list(s)
+        seen += mine
+        assert len(mine) == len(ref)
+    assert set(seen) == set(range(n))
+    assert shard_indices(10, 0, 0, 1, 2, shuffle=False).tolist() == [1, 3, 5, 7, 9]
+
+
+def _dp_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    from cerebralsignalnetworks_amd.trainer import FlatGrads, dist_info
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Tanh(), torch.nn.Linear(5, 3))
+    for p in model.parameters():
+        dist.broadcast(p.data, src=0)
+    fg = FlatGrads(model.parameters())
+    x = torch.arange(24, dtype=torch.float32).reshape(4, 6) / 10 + rank        # each rank: its own shard
+    fg.zero()
+    model(x).pow(2).mean().backward()
+    fg.all_reduce_mean()
+    assert dist_info() == (rank, world)
+    out[rank] = fg.flat.clone().numpy()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_flat_gradient_allreduce_two_process_gloo():
+    world, port = 2, 29611
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_dp_worker, args=(world, port, out), nprocs=world, join=True)
+    # single-process reference: mean of the per-shard gradients == gradient of the mean loss over both shards
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Tanh(), torch.nn.Linear(5, 3))
+    grads = []
+    for r in range(world):
+        model.zero_grad()
+        x = torch.arange(24, dtype=torch.float32).reshape(4, 6) / 10 + r
+        model(x).pow(2).mean().backward()
+        grads.append(torch.cat([p.grad.reshape(-1) for p in model.parameters()]).numpy().copy())
+    want = np.mean(grads, axis=0)
+    for r in range(world):
+        np.testing.assert_allclose(out[r], want, rtol=1e-6, atol=1e-7)
+    np.testing.assert_array_equal(out[0], out[1])
