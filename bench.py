@@ -56,35 +56,6 @@ def synthetic_pool(n, C, T, D, rank, device):
     return x.to(device), tg.to(device), lab.to(device)
 
 
-def time_cell_kernels(args, device, dtype):
-    """Average launch duration of the per-timestep cell kernels, HIP events on the launch stream."""
-    from cerebralsignalnetworks_amd import cabi
-    B, H = args.batch, args.hidden
-    w = (torch.randn(4 * H, H, device=device) / np.sqrt(H)).to(dtype)
-    wt = w.t().contiguous()
-    h = torch.randn(B, H, device=device).to(dtype)
-    c = torch.randn(B, H, device=device)
-    xp = torch.randn(B, 4 * H, device=device)
-    dg = (torch.randn(B, 4 * H, device=device) * 0.1).to(dtype)
-    gates = torch.rand(B, 4 * H, device=device).to(dtype)
-    dcar = torch.zeros(B, H, device=device)
-    out = {}
-    n = 200
-    for name, fn in (("fwd", lambda: cabi.lstm_cell_forward(h, w, xp, c)),
-                     ("bwd", lambda: cabi.lstm_cell_backward(dg, wt, None, gates, c, c, dcar))):
-        for _ in range(10):
-            fn()
-        st = torch.cuda.current_stream()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(st)
-        for _ in range(n):
-            fn()
-        e1.record(st)
-        e1.synchronize()
-        out[name] = e0.elapsed_time(e1) * 1e-3 / n
-    return out
-
-
 def log(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
@@ -122,6 +93,10 @@ def main():
         step(i)
         torch.cuda.synchronize()
         log(f"warm-up step {i} done")
+    from cerebralsignalnetworks_amd import cabi
+    if rank == 0 and not args.no_kernel_timing:
+        cabi.lstm_profile_enable(True)       # HIP events around the recurrence launch loops (same stream)
+    prof = []
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -129,6 +104,8 @@ def main():
     loss = None
     for i in range(args.steps):
         loss = step(args.warmup + i)
+        if rank == 0 and not args.no_kernel_timing and i == args.steps - 1:
+            pass
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -156,20 +133,21 @@ def main():
             "model_tflops": seg_per_s * flops_per_seg / 1e12,
         }
         if not args.no_kernel_timing:
-            kt = time_cell_kernels(args, device, dtype)
-            log(f"cell kernel timing: {kt}")
-            # dominant kernel: the backward cell step (K = 4H per launch); algorithmic flops per launch
-            fl_fwd = 2.0 * B * 4 * H * H
-            fl_bwd = 2.0 * B * 4 * H * H
-            dom = "bwd" if kt["bwd"] >= kt["fwd"] else "fwd"
-            ach = (fl_bwd if dom == "bwd" else fl_fwd) / kt[dom] / 1e12
-            res["roofline"] = {"bound": "mfma", "kernel": f"lstm_cell_{dom}_kernel", "achieved": ach,
-                               "peak": MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else 157.3,
-                               "unit": "TFLOP/s",
-                               "frac": ach / (MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else 157.3),
-                               "traffic": None,
-                               "us_per_launch": {k: v * 1e6 for k, v in kt.items()},
-                               "flops_per_launch": fl_bwd if dom == "bwd" else fl_fwd}
+            # dominant kernel = the backward cell launch (one per wavefront diagonal); its average duration
+            # comes from HIP events recorded on the launch stream around the recurrence of the LAST timed step
+            pr = cabi.lstm_profile_read()
+            peak = MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else 157.3
+            us = {k: (1e3 * pr[k + "_ms"] / max(1, pr[k + "_launches"])) for k in ("fwd", "bwd")}
+            dom = "bwd" if us["bwd"] >= us["fwd"] else "fwd"
+            cells_per_launch = pr[dom + "_cells"] / max(1, pr[dom + "_launches"])
+            flops_per_launch = 2.0 * B * 4 * H * H * cells_per_launch     # one recurrent product per cell problem
+            ach = flops_per_launch / (us[dom] * 1e-6) / 1e12
+            res["roofline"] = {"bound": "mfma", "kernel": f"lstm_cell_{dom}_il_kernel", "achieved": ach, "peak": peak,
+                               "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
+                               "us_per_launch": us, "launches": {k: pr[k + "_launches"] for k in ("fwd", "bwd")},
+                               "cells_per_launch": cells_per_launch, "flops_per_launch": flops_per_launch,
+                               "note": "per-timestep recurrent GEMM; limited by operand loads at the per-CU L2 rate "
+                                       "and the launch boundary, not by MFMA issue (DESIGN.md)"}
         if world == 1 and not args.no_cpu_baseline:
             from oracle import cpu_path, eeg_filter
             log(f"CPU baseline on {cpu_path.usable_cores()} cores")

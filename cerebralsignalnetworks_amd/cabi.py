@@ -41,6 +41,9 @@ SIGNATURES = {
                                    ctypes.POINTER(_c_void_p), ctypes.POINTER(_c_void_p),
                                    ctypes.POINTER(_c_void_p), ctypes.POINTER(_c_void_p),
                                    _c_void_p, _c_void_p]),
+    "csn_lstm_profile_enable": (_c_int, [_c_int]),
+    "csn_lstm_profile_read": (_c_int, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_c_int), ctypes.POINTER(_c_int),
+                                       ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_c_int), ctypes.POINTER(_c_int)]),
     "csn_gemm_nt": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_i64, _c_i64, _c_i64,
                              _c_int, _c_int, _c_int, _c_void_p]),
     "csn_gemm_tn_scratch_bytes": (_c_size_t, [_c_i64, _c_i64, _c_i64]),
@@ -230,6 +233,20 @@ class LstmPlan:
         _check(load().csn_lstm_backward(ctypes.byref(d), _ptr(dy_last), _ptr(dy_all), self._ws_ptr,
                                         _ptr_array(grads[0]), _ptr_array(grads[1]), _ptr_array(grads[2]),
                                         _ptr_array(grads[3]), _ptr(dx), _stream()))
+
+
+def lstm_profile_enable(on=True):
+    _check(load().csn_lstm_profile_enable(int(on)))
+
+
+def lstm_profile_read():
+    """-> dict(fwd_ms, fwd_launches, fwd_cells, bwd_ms, bwd_launches, bwd_cells) of the last fwd/bwd."""
+    fm, bm = ctypes.c_double(), ctypes.c_double()
+    fl, fc, bl, bc = _c_int(), _c_int(), _c_int(), _c_int()
+    _check(load().csn_lstm_profile_read(ctypes.byref(fm), ctypes.byref(fl), ctypes.byref(fc),
+                                        ctypes.byref(bm), ctypes.byref(bl), ctypes.byref(bc)))
+    return dict(fwd_ms=fm.value, fwd_launches=fl.value, fwd_cells=fc.value,
+                bwd_ms=bm.value, bwd_launches=bl.value, bwd_cells=bc.value)
 
 
 def cosine_loss(student, teacher, want_grad=True, grad_scale=1.0):

@@ -188,6 +188,21 @@ static int hand_off(SideCtx* c, hipStream_t from, hipStream_t to) {
   return CSN_OK;
 }
 
+// ---- optional event timing of the recurrence window ----------------------------------------
+struct Prof {
+  bool on = false;
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};   // fwd begin/end, bwd begin/end
+  int launches[2] = {0, 0}, cells[2] = {0, 0};
+  bool have[2] = {false, false};
+};
+static Prof g_prof;
+static int prof_mark(int which, hipStream_t st) {
+  if (!g_prof.on) return CSN_OK;
+  if (g_prof.ev[which] == nullptr) CSN_HIP_CHECK(hipEventCreate(&g_prof.ev[which]));
+  CSN_HIP_CHECK(hipEventRecord(g_prof.ev[which], st));
+  return CSN_OK;
+}
+
 static int chunk_steps() {
   const char* e = getenv("CSN_LSTM_CHUNK");
   int c = e ? atoi(e) : 32;
@@ -197,6 +212,30 @@ static int chunk_steps() {
 }  // namespace csn
 
 using namespace csn;
+
+extern "C" int csn_lstm_profile_enable(int on) {
+  g_prof.on = on != 0;
+  g_prof.have[0] = g_prof.have[1] = false;
+  return CSN_OK;
+}
+
+extern "C" int csn_lstm_profile_read(double* fwd_ms, int* fwd_launches, int* fwd_cells, double* bwd_ms,
+                                     int* bwd_launches, int* bwd_cells) {
+  CSN_REQUIRE(fwd_ms && fwd_launches && fwd_cells && bwd_ms && bwd_launches && bwd_cells,
+              "csn_lstm_profile_read: null pointer");
+  *fwd_ms = *bwd_ms = 0.0;
+  *fwd_launches = *fwd_cells = *bwd_launches = *bwd_cells = 0;
+  for (int k = 0; k < 2; ++k) {
+    if (!g_prof.have[k]) continue;
+    float ms = 0.f;
+    CSN_HIP_CHECK(hipEventSynchronize(g_prof.ev[2 * k + 1]));
+    CSN_HIP_CHECK(hipEventElapsedTime(&ms, g_prof.ev[2 * k], g_prof.ev[2 * k + 1]));
+    (k == 0 ? *fwd_ms : *bwd_ms) = ms;
+    (k == 0 ? *fwd_launches : *bwd_launches) = g_prof.launches[k];
+    (k == 0 ? *fwd_cells : *bwd_cells) = g_prof.cells[k];
+  }
+  return CSN_OK;
+}
 
 extern "C" size_t csn_lstm_workspace_bytes(const csnLstmDesc* d, int training) {
   if (check_desc("csn_lstm_workspace_bytes", d) != CSN_OK) return 0;
@@ -328,6 +367,8 @@ static int forward_il(const csnLstmDesc* d, const WsLayout& w, char* ws, const f
   const int nch = (T + Cz - 1) / Cz;
   std::vector<hipEvent_t> xproj_ready((size_t)NL * nch, nullptr);
   const int D = T + lag * (NL - 1);
+  int n_launch = 0, n_cells = 0;
+  if ((rc = prof_mark(0, st))) return rc;
   for (int dg = 0; dg < D; ++dg) {
     CellFwdArgs a{};
     a.B = B;
@@ -350,6 +391,8 @@ static int forward_il(const csnLstmDesc* d, const WsLayout& w, char* ws, const f
     }
     if (np == 0) continue;
     if ((rc = launch_cell_fwd_il(a, np, st))) return rc;
+    ++n_launch;
+    n_cells += np;
     // a layer that just finished a chunk feeds the next layer's input projection (side stream)
     for (int l = 0; l + 1 < NL; ++l) {
       const int t = dg - lag * l;
@@ -368,6 +411,10 @@ static int forward_il(const csnLstmDesc* d, const WsLayout& w, char* ws, const f
       xproj_ready[(size_t)(l + 1) * nch + c] = ev;
     }
   }
+  if ((rc = prof_mark(1, st))) return rc;
+  g_prof.launches[0] = n_launch;
+  g_prof.cells[0] = n_cells;
+  g_prof.have[0] = g_prof.on;
   return CSN_OK;
 }
 
@@ -414,6 +461,8 @@ static int backward_il(const csnLstmDesc* d, const WsLayout& w, char* ws, const 
 
   std::vector<hipEvent_t> dx_ready((size_t)NL * nch, nullptr);
   const int D = T + lag * (NL - 1);
+  int n_launch = 0, n_cells = 0;
+  if ((rc = prof_mark(2, st))) return rc;
   for (int dg = 0; dg < D; ++dg) {
     CellBwdArgs a{};
     a.B = B;
@@ -444,6 +493,8 @@ static int backward_il(const csnLstmDesc* d, const WsLayout& w, char* ws, const 
     }
     if (np == 0) continue;
     if ((rc = launch_cell_bwd_il(a, np, st))) return rc;
+    ++n_launch;
+    n_cells += np;
     for (int l = NL - 1; l >= 0; --l) {
       const int r = dg - lag * (NL - 1 - l);
       if (r < 0 || r >= T) continue;
@@ -477,6 +528,10 @@ static int backward_il(const csnLstmDesc* d, const WsLayout& w, char* ws, const 
       if (last && (rc = weight_grads(l))) return rc;
     }
   }
+  if ((rc = prof_mark(3, st))) return rc;
+  g_prof.launches[1] = n_launch;
+  g_prof.cells[1] = n_cells;
+  g_prof.have[1] = g_prof.on;
   return hand_off(sc, side, st);   // the caller's stream resumes after all side-stream work
 }
 

@@ -101,6 +101,14 @@ int csn_lstm_backward(const csnLstmDesc* d,
                       float* const* db_ih, float* const* db_hh,
                       float* dx, csnStream_t stream);
 
+/* Optional timing of the recurrence (the stream of per-timestep cell launches) with HIP events
+ * recorded on the caller's stream around the launch loop of the most recent forward / backward.
+ * csn_lstm_profile_read synchronises on those events; *_launches = cell launches in the window;
+ * *_cells = cell problems (layer-steps) those launches advanced. */
+int csn_lstm_profile_enable(int on);
+int csn_lstm_profile_read(double* fwd_ms, int* fwd_launches, int* fwd_cells,
+                          double* bwd_ms, int* bwd_launches, int* bwd_cells);
+
 /* ------------------------------------------------------------------------------------
  * Building blocks of K3, exported so that each can be parity-tested on its own.
  * ---------------------------------------------------------------------------------- */
