@@ -42,6 +42,35 @@ __device__ unsigned long long* g_stamps = nullptr;
 #define CSN_STAMP(i)
 #endif
 
+// Streaming (touched-once) epilogue traffic -- xproj, saved gates, c, row-major h / dgates --
+// is marked non-temporal so it does not displace the re-read operands (W, h) from L2 and leaves
+// fewer dirty lines for the end-of-kernel write-back.
+#ifndef CSN_NT
+#define CSN_NT 1
+#endif
+template <typename V> __device__ __forceinline__ V nt_load(const V* p) {
+#if CSN_NT
+  return __builtin_nontemporal_load(p);
+#else
+  return *p;
+#endif
+}
+template <typename V> __device__ __forceinline__ void nt_store(V* p, const V& v) {
+#if CSN_NT
+  __builtin_nontemporal_store(v, p);
+#else
+  *p = v;
+#endif
+}
+// float4 (a HIP struct type) goes through the equivalent clang vector type
+__device__ __forceinline__ float4 nt_load(const float4* p) {
+  const csn::f32x4 v = nt_load(reinterpret_cast<const csn::f32x4*>(p));
+  return make_float4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ void nt_store(float4* p, const float4& v) {
+  nt_store(reinterpret_cast<csn::f32x4*>(p), (csn::f32x4){v.x, v.y, v.z, v.w});
+}
+
 namespace csn {
 
 // ------------------------------------------------------------------------------------------
@@ -172,7 +201,7 @@ __global__ void __launch_bounds__(256) lstm_cell_fwd_il_kernel(CellFwdArgs a) {
     if (p < NPAIR && row < B) {
       const float4* xr = reinterpret_cast<const float4*>(P.xproj + (int64_t)row * 4 * H + 4 * (int64_t)uq);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) xp[ps][q] = xr[q];
+      for (int q = 0; q < 4; ++q) xp[ps][q] = nt_load(xr + q);
       if (P.c_prev != nullptr) cp[ps] = *reinterpret_cast<const float4*>(P.c_prev + (int64_t)row * H + uq);
     }
   }
@@ -265,11 +294,14 @@ __global__ void __launch_bounds__(256) lstm_cell_fwd_il_kernel(CellFwdArgs a) {
       bf16x8 lo = {(bf16_t)gi[0], (bf16_t)gf[0], (bf16_t)gg[0], (bf16_t)go[0], (bf16_t)gi[1], (bf16_t)gf[1], (bf16_t)gg[1], (bf16_t)go[1]};
       bf16x8 hi = {(bf16_t)gi[2], (bf16_t)gf[2], (bf16_t)gg[2], (bf16_t)go[2], (bf16_t)gi[3], (bf16_t)gf[3], (bf16_t)gg[3], (bf16_t)go[3]};
       bf16x8* gp = reinterpret_cast<bf16x8*>(P.gates_out + (int64_t)row * 4 * H + 4 * (int64_t)uq);
-      gp[0] = lo;
-      gp[1] = hi;
+      nt_store(gp, lo);
+      nt_store(gp + 1, hi);
     }
-    Vec4<float>::store(P.c_out + (int64_t)row * H + uq, cn);
-    Vec4<bf16_t>::store(P.h_out + (int64_t)row * H + uq, hn);
+    nt_store(reinterpret_cast<float4*>(P.c_out + (int64_t)row * H + uq), make_float4(cn[0], cn[1], cn[2], cn[3]));
+    {
+      bf16x4 hv = {(bf16_t)hn[0], (bf16_t)hn[1], (bf16_t)hn[2], (bf16_t)hn[3]};
+      nt_store(reinterpret_cast<bf16x4*>(P.h_out + (int64_t)row * H + uq), hv);
+    }
     Vec4<bf16_t>::store(P.h_out_blk + blk_offset(row, uq, H), hn);
   }
   CSN_STAMP(3);
@@ -302,8 +334,8 @@ __global__ void __launch_bounds__(256) lstm_cell_bwd_il_kernel(CellBwdArgs a) {
     dyv[ps] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (p < NPAIR && row < B) {
       const bf16x8* gp = reinterpret_cast<const bf16x8*>(P.gates + (int64_t)row * K + 4 * (int64_t)uq);
-      gt[ps][0] = gp[0];
-      gt[ps][1] = gp[1];
+      gt[ps][0] = nt_load(gp);
+      gt[ps][1] = nt_load(gp + 1);
       cc[ps] = *reinterpret_cast<const float4*>(P.c + (int64_t)row * H + uq);
       if (P.c_prev != nullptr) cpv[ps] = *reinterpret_cast<const float4*>(P.c_prev + (int64_t)row * H + uq);
       dcn[ps] = *reinterpret_cast<const float4*>(P.dc_carry + (int64_t)row * H + uq);
@@ -408,8 +440,8 @@ __global__ void __launch_bounds__(256) lstm_cell_bwd_il_kernel(CellBwdArgs a) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) { lo[e] = (bf16_t)out[e]; hi[e] = (bf16_t)out[8 + e]; }
     bf16x8* op = reinterpret_cast<bf16x8*>(P.dg_out + (int64_t)row * K + 4 * (int64_t)uq);
-    op[0] = lo;
-    op[1] = hi;
+    nt_store(op, lo);
+    nt_store(op + 1, hi);
     *reinterpret_cast<bf16x8*>(P.dg_out_blk + blk_offset(row, 4 * (int64_t)uq, K)) = lo;
     *reinterpret_cast<bf16x8*>(P.dg_out_blk + blk_offset(row, 4 * (int64_t)uq + 8, K)) = hi;
     Vec4<float>::store(P.dc_carry + (int64_t)row * H + uq, dcarry);
