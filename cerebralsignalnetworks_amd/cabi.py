@@ -41,6 +41,7 @@ SIGNATURES = {
                                    ctypes.POINTER(_c_void_p), ctypes.POINTER(_c_void_p),
                                    ctypes.POINTER(_c_void_p), ctypes.POINTER(_c_void_p),
                                    _c_void_p, _c_void_p]),
+    "csn_lstm_read_status": (_c_int, [ctypes.POINTER(LstmDesc), _c_void_p, _c_int, ctypes.POINTER(_c_int)]),
     "csn_lstm_profile_enable": (_c_int, [_c_int]),
     "csn_lstm_profile_read": (_c_int, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_c_int), ctypes.POINTER(_c_int),
                                        ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_c_int), ctypes.POINTER(_c_int)]),
@@ -222,6 +223,12 @@ class LstmPlan:
                                        _ptr_array(ws[0]), _ptr_array(ws[1]), _ptr_array(ws[2]), _ptr_array(ws[3]),
                                        self._ws_ptr, int(self.training), _ptr(y_last), _ptr(y_all), _stream()))
         return y_last, y_all
+
+    def status(self):
+        """Blocking: 0 if the last forward's in-kernel hand-offs all completed."""
+        out = _c_int(0)
+        _check(load().csn_lstm_read_status(ctypes.byref(self.desc), self._ws_ptr, int(self.training), ctypes.byref(out)))
+        return out.value
 
     def backward(self, dy_last, dy_all, grads, dx=None):
         """grads: 4 lists (dw_ih, dw_hh, db_ih, db_hh) of float32 device tensors, overwritten."""

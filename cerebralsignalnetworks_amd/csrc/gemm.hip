@@ -121,11 +121,14 @@ __device__ __forceinline__ int nt_lds_off(int row, int chunk) {  // byte offset 
   return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
 }
 
-template <typename OutT>
+// NBUF = 2: double-buffered LDS (64 KB, one barrier per k-tile).  NBUF = 1: one 32 KB buffer, two
+// barriers per k-tile -- small enough to co-reside on a CU with the weight-stationary LSTM kernel
+// (100 KB LDS), which is how the input-projection GEMMs overlap the recurrence.
+template <typename OutT, int NBUF>
 __global__ void __launch_bounds__(256)
 gemm_nt_bf16_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ Bt, const float* __restrict__ bias,
                     OutT* __restrict__ C, int64_t M, int64_t N, int64_t K, int accumulate) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 buffers x (A 16 KB + B 16 KB)
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // NBUF buffers x (A 16 KB + B 16 KB)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int64_t m0 = (int64_t)blockIdx.y * 128, n0 = (int64_t)blockIdx.x * 128;
@@ -167,7 +170,7 @@ gemm_nt_bf16_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ Bt,
   store_tile(0);
   __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
+    const int buf = (NBUF == 2) ? (kt & 1) : 0;
     if (kt + 1 < nk) load_tile(kt + 1);
     const char* a_s = smem + buf * 32768;
     const char* b_s = a_s + 16384;
@@ -187,7 +190,8 @@ gemm_nt_bf16_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ Bt,
           // swapped operands: D[row = n][col = m]: lane holds m = lane&15, n = (lane>>4)*4 + r
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
     }
-    if (kt + 1 < nk) store_tile(buf ^ 1);
+    if (NBUF == 1) __syncthreads();           // everyone has read the tile before it is overwritten
+    if (kt + 1 < nk) store_tile(NBUF == 2 ? (buf ^ 1) : 0);
     __syncthreads();
   }
 
@@ -380,12 +384,14 @@ extern "C" int csn_gemm_nt(const void* A, const void* Bt, const float* bias, voi
   if (!fast)
     return launch_generic(A, K, 1, Bt, 1, K, bias, C, N, M, N, K, dtype, out_dtype, accumulate, 1, 0, st);
   dim3 grid((unsigned)((N + 127) / 128), (unsigned)((M + 127) / 128));
-  if (out_dtype == CSN_BF16)
-    gemm_nt_bf16_kernel<bf16_t><<<grid, 256, 65536, st>>>((const bf16_t*)A, (const bf16_t*)Bt, bias, (bf16_t*)C, M, N,
-                                                          K, 0);
-  else
-    gemm_nt_bf16_kernel<float><<<grid, 256, 65536, st>>>((const bf16_t*)A, (const bf16_t*)Bt, bias, (float*)C, M, N, K,
-                                                         accumulate);
+  const bool two = getenv("CSN_GEMM_LDS64") != nullptr;
+  if (out_dtype == CSN_BF16) {
+    if (two) gemm_nt_bf16_kernel<bf16_t, 2><<<grid, 256, 65536, st>>>((const bf16_t*)A, (const bf16_t*)Bt, bias, (bf16_t*)C, M, N, K, 0);
+    else gemm_nt_bf16_kernel<bf16_t, 1><<<grid, 256, 32768, st>>>((const bf16_t*)A, (const bf16_t*)Bt, bias, (bf16_t*)C, M, N, K, 0);
+  } else {
+    if (two) gemm_nt_bf16_kernel<float, 2><<<grid, 256, 65536, st>>>((const bf16_t*)A, (const bf16_t*)Bt, bias, (float*)C, M, N, K, accumulate);
+    else gemm_nt_bf16_kernel<float, 1><<<grid, 256, 32768, st>>>((const bf16_t*)A, (const bf16_t*)Bt, bias, (float*)C, M, N, K, accumulate);
+  }
   CSN_LAUNCH_CHECK();
   return CSN_OK;
 }

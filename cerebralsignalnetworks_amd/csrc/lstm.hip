@@ -38,17 +38,18 @@ int launch_cell_bwd(const void* dg_next, const void* w_hh_t, const float* dy, in
 
 struct LayerWs {
   size_t wih, whh, whht, wiht, whh_blk, whht_blk, bias, xproj, gates, c_all, h_all, dgates, dx, dc_carry, hblk[2],
-      dgblk[2];
+      dgblk[2], h_blk_all, counters;
 };
 struct WsLayout {
   LayerWs layer[8];
-  size_t x_c, dy_tm, tn_scratch, colsum, total;
-  bool il;
+  size_t x_c, dy_tm, tn_scratch, colsum, status, total;
+  bool il, persist;
 };
 
 static WsLayout make_layout(const csnLstmDesc& d, int training) {
   WsLayout w{};
   w.il = cell_blk_supported(d.H, d.dtype);
+  w.persist = w.il && fwd_persist_supported(d.B, d.H, d.dtype) && d.L <= 4;
   size_t off = 0;
   const size_t es = dtype_size(d.dtype);
   auto take = [&](size_t bytes) {
@@ -70,6 +71,10 @@ static WsLayout make_layout(const csnLstmDesc& d, int training) {
       L.whht_blk = take(G * H * 2);
       L.hblk[0] = take(Bpad * H * 2);
       L.hblk[1] = take(Bpad * H * 2);
+      if (w.persist) {
+        L.h_blk_all = take(((size_t)d.T + 1) * Bpad * H * 2);
+        L.counters = take(((size_t)d.T + 1) * (Bpad / 64) * 4);
+      }
     } else {
       L.whh = take(G * H * es);
       L.whht = take(G * H * es);
@@ -92,6 +97,7 @@ static WsLayout make_layout(const csnLstmDesc& d, int training) {
     if (b > tn_bytes) tn_bytes = b;
   }
   w.x_c = take(TB * d.I * es);
+  w.status = take(256);
   if (training) {
     w.dy_tm = take(TB * H * 4);
     w.tn_scratch = take(tn_bytes);
@@ -154,7 +160,8 @@ static inline unsigned grid_for(int64_t n) {
 
 // ---- second stream + event pool (library-owned, created on first use, per device) ------------
 struct SideCtx {
-  hipStream_t side = nullptr;
+  hipStream_t side = nullptr;           // GEMMs
+  hipStream_t layer[8] = {nullptr};     // weight-stationary forward: one stream per layer >= 1
   std::vector<hipEvent_t> events;
   size_t next = 0;
 };
@@ -165,7 +172,10 @@ static int side_ctx(SideCtx** out) {
   CSN_HIP_CHECK(hipGetDevice(&dev));
   CSN_REQUIRE(dev >= 0 && dev < 16, "device index %d out of range", dev);
   SideCtx& c = g_side[dev];
-  if (c.side == nullptr) CSN_HIP_CHECK(hipStreamCreateWithFlags(&c.side, hipStreamNonBlocking));
+  if (c.side == nullptr) {
+    CSN_HIP_CHECK(hipStreamCreateWithFlags(&c.side, hipStreamNonBlocking));
+    for (int l = 1; l < 8; ++l) CSN_HIP_CHECK(hipStreamCreateWithFlags(&c.layer[l], hipStreamNonBlocking));
+  }
   c.next = 0;
   *out = &c;
   return CSN_OK;
@@ -234,6 +244,16 @@ extern "C" int csn_lstm_profile_read(double* fwd_ms, int* fwd_launches, int* fwd
     (k == 0 ? *fwd_launches : *bwd_launches) = g_prof.launches[k];
     (k == 0 ? *fwd_cells : *bwd_cells) = g_prof.cells[k];
   }
+  return CSN_OK;
+}
+
+extern "C" int csn_lstm_read_status(const csnLstmDesc* d, const void* workspace, int training, int* status) {
+  if (int rc = check_desc("csn_lstm_read_status", d)) return rc;
+  CSN_REQUIRE(workspace && status, "csn_lstm_read_status: null pointer");
+  const WsLayout w = make_layout(*d, training);
+  unsigned flag = 0;
+  CSN_HIP_CHECK(hipMemcpy(&flag, (const char*)workspace + w.status, sizeof(flag), hipMemcpyDeviceToHost));
+  *status = (int)flag;
   return CSN_OK;
 }
 
@@ -328,6 +348,9 @@ static int backward_v1(const csnLstmDesc* d, const WsLayout& w, char* ws, const 
 // =============================================================================================
 // il fast path (wavefront over layers, GEMMs on the side stream)
 // =============================================================================================
+static int forward_persist(const csnLstmDesc* d, const WsLayout& w, char* ws, int training, hipStream_t st,
+                           SideCtx* sc, hipStream_t side);
+
 static int forward_il(const csnLstmDesc* d, const WsLayout& w, char* ws, const float* x, int64_t xsb, int64_t xst,
                       const float* const* w_ih, const float* const* w_hh, const float* const* b_ih,
                       const float* const* b_hh, int training, csnStream_t stream) {
@@ -362,6 +385,7 @@ static int forward_il(const csnLstmDesc* d, const WsLayout& w, char* ws, const f
   if ((rc = csn_gemm_nt(ws + w.x_c, ws + w.layer[0].wih, (const float*)(ws + w.layer[0].bias), ws + w.layer[0].xproj,
                         TB, G, d->I, CSN_BF16, CSN_F32, 0, stream)))
     return rc;
+  if (w.persist) return forward_persist(d, w, ws, training, st, sc, side);
   if (NL > 1 && (rc = hand_off(sc, st, side))) return rc;   // side stream sees the prepared weights
 
   const int nch = (T + Cz - 1) / Cz;
@@ -414,6 +438,72 @@ static int forward_il(const csnLstmDesc* d, const WsLayout& w, char* ws, const f
   if ((rc = prof_mark(1, st))) return rc;
   g_prof.launches[0] = n_launch;
   g_prof.cells[0] = n_cells;
+  g_prof.have[0] = g_prof.on;
+  return CSN_OK;
+}
+
+// Weight-stationary forward (lstm_fwd_persist.hip): layer l runs chunk after chunk on its own stream,
+// the input projection of layer l+1 for a chunk is a GEMM on the side stream as soon as layer l has
+// finished that chunk, and layer l+1's chunk kernel waits for that GEMM.  The two layers' persistent
+// kernels (128 workgroups each at cfg2) occupy all 256 CUs; the GEMM workgroups co-reside with them
+// (registers 408 + 96 per SIMD lane, LDS 100 + 32 KB per CU).
+static int forward_persist(const csnLstmDesc* d, const WsLayout& w, char* ws, int training, hipStream_t st,
+                           SideCtx* sc, hipStream_t side) {
+  const int B = d->B, T = d->T, H = d->H, NL = d->L;
+  const int64_t G = 4 * (int64_t)H;
+  const int Bpad = (B + 63) / 64 * 64, MT = Bpad / 64;
+  const int Cz = chunk_steps();
+  const int nch = (T + Cz - 1) / Cz;
+  int rc;
+  for (int l = 0; l < NL; ++l)
+    CSN_HIP_CHECK(hipMemsetAsync(ws + w.layer[l].counters, 0, ((size_t)T + 1) * MT * 4, st));
+  hipStream_t ls[8];
+  ls[0] = st;
+  for (int l = 1; l < NL; ++l) {
+    ls[l] = (side == st) ? st : sc->layer[l];
+    if (ls[l] != st && (rc = hand_off(sc, st, ls[l]))) return rc;
+  }
+  if (side != st && (rc = hand_off(sc, st, side))) return rc;
+  int n_launch = 0;
+  const bool gemm_slot = getenv("CSN_GEMM_SLOT") != nullptr;
+  if ((rc = prof_mark(0, st))) return rc;
+  for (int c = 0; c < nch; ++c) {
+    const int t0 = c * Cz, nsteps = (t0 + Cz <= T) ? Cz : T - t0;
+    for (int l = 0; l < NL; ++l) {
+      const LayerWs& L = w.layer[l];
+      PersistFwdArgs a{};
+      a.w_blk = (const bf16_t*)(ws + L.whh_blk);
+      a.xproj = (const float*)(ws + L.xproj);
+      a.gates = training ? (bf16_t*)(ws + L.gates) : nullptr;
+      a.c_all = (float*)(ws + L.c_all);
+      a.h_all = (bf16_t*)(ws + L.h_all);
+      a.h_blk_all = (bf16_t*)(ws + L.h_blk_all);
+      a.counters = (unsigned*)(ws + L.counters);
+      a.error_flag = (unsigned*)(ws + w.status);
+      a.B = B; a.H = H; a.T = T; a.t0 = t0; a.nsteps = nsteps; a.Bpad = Bpad;
+      if ((rc = launch_fwd_persist(a, ls[l]))) return rc;
+      ++n_launch;
+      if (l + 1 < NL) {
+        // layer l finished chunk c -> GEMM xproj_{l+1}[chunk] on the side stream -> layer l+1 may start it
+        if ((rc = hand_off(sc, ls[l], side))) return rc;
+        const LayerWs& Ln = w.layer[l + 1];
+        rc = csn_gemm_nt((const bf16_t*)(ws + L.h_all) + (size_t)(t0 + 1) * B * H, ws + Ln.wih,
+                         (const float*)(ws + Ln.bias), (float*)(ws + Ln.xproj) + (size_t)t0 * B * G,
+                         (int64_t)nsteps * B, G, H, CSN_BF16, CSN_F32, 0, (csnStream_t)side);
+        if (rc) return rc;
+        if (side != ls[l + 1] && (rc = hand_off(sc, side, ls[l + 1]))) return rc;
+        // optional: the producing layer's next chunk also waits, so the GEMM runs in a slot of its own
+        if (gemm_slot && side != ls[l] && (rc = hand_off(sc, side, ls[l]))) return rc;
+      }
+    }
+  }
+  // the caller's stream resumes after every layer stream (and the side stream) has drained
+  for (int l = 1; l < NL; ++l)
+    if (ls[l] != st && (rc = hand_off(sc, ls[l], st))) return rc;
+  if (side != st && (rc = hand_off(sc, side, st))) return rc;
+  if ((rc = prof_mark(1, st))) return rc;
+  g_prof.launches[0] = n_launch;
+  g_prof.cells[0] = T * NL;
   g_prof.have[0] = g_prof.on;
   return CSN_OK;
 }
@@ -552,6 +642,7 @@ extern "C" int csn_lstm_forward(const csnLstmDesc* d, const float* x, int64_t x_
   const int B = d->B, T = d->T, H = d->H, dt = d->dtype;
   const size_t es = dtype_size(dt);
   int rc;
+  CSN_HIP_CHECK(hipMemsetAsync(ws + w.status, 0, 256, st));
   if (w.il)
     rc = forward_il(d, w, ws, x, x_stride_b, x_stride_t, w_ih, w_hh, b_ih, b_hh, training, stream);
   else

@@ -36,6 +36,21 @@ struct CellBwdArgs {
   int B, H;
 };
 
+// weight-stationary forward over a chunk of timesteps of ONE layer (lstm_fwd_persist.hip)
+struct PersistFwdArgs {
+  const bf16_t* w_blk;     // fragment-major W_hh, interleaved rows [4H, H]
+  const float* xproj;      // [T, B, 4H] interleaved
+  bf16_t* gates;           // [T, B, 4H] interleaved, or null
+  float* c_all;            // [T+1, B, H]  (slot t+1 = c_t)
+  bf16_t* h_all;           // [T+1, B, H]  row-major
+  bf16_t* h_blk_all;       // [T+1][Bpad * H] fragment-major slabs (slot t+1 = h_t); never reused in a forward
+  unsigned* counters;      // [T+1][MT] arrivals per (slot, M-tile), zeroed before the first chunk
+  unsigned* error_flag;    // sticky: a bounded spin gave up
+  int B, H, T, t0, nsteps, Bpad;
+};
+bool fwd_persist_supported(int B, int H, int dtype);
+int launch_fwd_persist(const PersistFwdArgs& a, hipStream_t st);
+
 bool cell_blk_supported(int H, int dtype);
 int launch_cell_fwd_il(const CellFwdArgs& a, int nprob, hipStream_t st);
 int launch_cell_bwd_il(const CellBwdArgs& a, int nprob, hipStream_t st);

@@ -42,35 +42,6 @@ __device__ unsigned long long* g_stamps = nullptr;
 #define CSN_STAMP(i)
 #endif
 
-// Streaming (touched-once) epilogue traffic -- xproj, saved gates, c, row-major h / dgates --
-// is marked non-temporal so it does not displace the re-read operands (W, h) from L2 and leaves
-// fewer dirty lines for the end-of-kernel write-back.
-#ifndef CSN_NT
-#define CSN_NT 1
-#endif
-template <typename V> __device__ __forceinline__ V nt_load(const V* p) {
-#if CSN_NT
-  return __builtin_nontemporal_load(p);
-#else
-  return *p;
-#endif
-}
-template <typename V> __device__ __forceinline__ void nt_store(V* p, const V& v) {
-#if CSN_NT
-  __builtin_nontemporal_store(v, p);
-#else
-  *p = v;
-#endif
-}
-// float4 (a HIP struct type) goes through the equivalent clang vector type
-__device__ __forceinline__ float4 nt_load(const float4* p) {
-  const csn::f32x4 v = nt_load(reinterpret_cast<const csn::f32x4*>(p));
-  return make_float4(v[0], v[1], v[2], v[3]);
-}
-__device__ __forceinline__ void nt_store(float4* p, const float4& v) {
-  nt_store(reinterpret_cast<csn::f32x4*>(p), (csn::f32x4){v.x, v.y, v.z, v.w});
-}
-
 namespace csn {
 
 // ------------------------------------------------------------------------------------------

@@ -101,6 +101,10 @@ int csn_lstm_backward(const csnLstmDesc* d,
                       float* const* db_ih, float* const* db_hh,
                       float* dx, csnStream_t stream);
 
+/* Blocking read (device -> host) of the workspace's status word after a forward: 0 = ok; non-zero =
+ * a bounded in-kernel wait of the weight-stationary forward gave up (results are invalid). */
+int csn_lstm_read_status(const csnLstmDesc* d, const void* workspace, int training, int* status);
+
 /* Optional timing of the recurrence (the stream of per-timestep cell launches) with HIP events
  * recorded on the caller's stream around the launch loop of the most recent forward / backward.
  * csn_lstm_profile_read synchronises on those events; *_launches = cell launches in the window;

@@ -397,6 +397,8 @@ def _run_lstm(p, x, dy_all, dy_last, C, H, L, dtype, cuda, env=None):
         loss = (y_all * dev_t(dy_all, cuda)).sum() + (y_last * dev_t(dy_last, cuda)).sum()
         loss.backward()
         torch.cuda.synchronize()
+        for plan in m.lstm._plans.values():
+            assert plan.status() == 0, "an in-kernel hand-off of the weight-stationary forward timed out"
         out = dict(y_all=y_all.detach().cpu().numpy(), dx=xt.grad.cpu().numpy())
         for n, q in m.lstm.named_parameters():
             out[n] = q.grad.cpu().numpy()
@@ -431,9 +433,13 @@ def test_fast_path_matches_oracle_and_v1(cuda, B, T, C, H, L, chunk):
     slow = _run_lstm(p, x, dy_all, dy_last, C, H, L, torch.bfloat16, cuda, {"CSN_CELL_V1": "1"})
     serial = _run_lstm(p, x, dy_all, dy_last, C, H, L, torch.bfloat16, cuda,
                        {"CSN_LSTM_CHUNK": chunk, "CSN_NO_SIDE_STREAM": "1"})
-    # the wavefront with side-stream GEMMs computes exactly what the single-stream schedule computes
+    diag = _run_lstm(p, x, dy_all, dy_last, C, H, L, torch.bfloat16, cuda,
+                     {"CSN_LSTM_CHUNK": chunk, "CSN_NO_PERSIST": "1"})
+    # multi-stream schedules compute exactly what the single-stream schedule computes, and the
+    # weight-stationary forward exactly what the per-diagonal launches compute
     for k in fast:
         np.testing.assert_array_equal(fast[k], serial[k], err_msg=k)
+        np.testing.assert_array_equal(fast[k], diag[k], err_msg=k)
     assert np.abs(fast["y_all"] - y).max() < 3e-2
     assert _rel(fast["dx"], dx_ref) < 4e-2
     for k, v in g_ref.items():
