@@ -110,6 +110,16 @@ static int launch_generic(const void* A, int64_t sam, int64_t sak, const void* B
   return CSN_OK;
 }
 
+// XCD-aware block order (cdna_hip_programming.md T1): hardware deals consecutive workgroups round-robin
+// over the 8 XCDs (each with a private L2), so tiles that share an operand panel would land on 8
+// different L2s and the panel would cross the fabric 8 times (measured with FETCH_SIZE: 12x the
+// algorithmic bytes on the NT GEMM, 4.5x on the TN GEMM).  This bijection hands every XCD one
+// contiguous range of the logical tile order instead.  Speed only -- any placement is correct.
+__device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nwg) {
+  const unsigned q = nwg >> 3, r = nwg & 7, xcd = bid & 7, slot = bid >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+}
+
 // =====================================================================================
 // bf16 NT GEMM, 128x128x64 tiles
 // =====================================================================================
@@ -131,7 +141,11 @@ gemm_nt_bf16_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ Bt,
   extern __shared__ __attribute__((aligned(16))) char smem[];  // NBUF buffers x (A 16 KB + B 16 KB)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int64_t m0 = (int64_t)blockIdx.y * 128, n0 = (int64_t)blockIdx.x * 128;
+  // logical order: N tiles fastest inside an M tile, so one XCD walks the N tiles of "its" M tiles and
+  // the A panel of an M tile is fetched into a single L2
+  const unsigned ntn = (unsigned)((N + 127) / 128);
+  const unsigned lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int64_t m0 = (int64_t)(lid / ntn) * 128, n0 = (int64_t)(lid % ntn) * 128;
   const int nk = (int)((K + 63) / 64);
 
   // global->register staging: each thread moves 4 chunks of A and 4 of B per k-tile.
@@ -276,8 +290,13 @@ gemm_tn_bf16_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ Bm,
   __shared__ __attribute__((aligned(16))) char smem[2 * 16384];  // 2 buffers x (A 8 KB + B 8 KB)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int64_t m0 = (int64_t)blockIdx.y * 128, n0 = (int64_t)blockIdx.x * 128;
-  const int64_t kbeg = (int64_t)blockIdx.z * k_per_split;
+  // logical order [split][m tile][n tile]: an XCD gets whole K splits (or contiguous parts of one), so
+  // the tiles that stream the same rows of A and B at the same time share one L2
+  const unsigned ntn = (unsigned)((N + 127) / 128), ntm = (unsigned)((M + 127) / 128);
+  const unsigned lid = xcd_remap(blockIdx.x, gridDim.x);
+  const unsigned zsplit = lid / (ntm * ntn), rem = lid % (ntm * ntn);
+  const int64_t m0 = (int64_t)(rem / ntn) * 128, n0 = (int64_t)(rem % ntn) * 128;
+  const int64_t kbeg = (int64_t)zsplit * k_per_split;
   const int64_t kend = (kbeg + k_per_split < K) ? kbeg + k_per_split : K;
   const int nk = (int)((kend - kbeg + 31) / 32);
 
@@ -336,7 +355,7 @@ gemm_tn_bf16_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ Bm,
     __syncthreads();
   }
 
-  float* C = slabs + (int64_t)blockIdx.z * M * N;
+  float* C = slabs + (int64_t)zsplit * M * N;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int64_t m = m0 + wm * 64 + i * 16 + (lane & 15);
@@ -383,7 +402,7 @@ extern "C" int csn_gemm_nt(const void* A, const void* Bt, const float* bias, voi
                     getenv("CSN_GEMM_GENERIC") == nullptr;
   if (!fast)
     return launch_generic(A, K, 1, Bt, 1, K, bias, C, N, M, N, K, dtype, out_dtype, accumulate, 1, 0, st);
-  dim3 grid((unsigned)((N + 127) / 128), (unsigned)((M + 127) / 128));
+  dim3 grid((unsigned)(((N + 127) / 128) * ((M + 127) / 128)));
   const bool two = getenv("CSN_GEMM_LDS64") != nullptr;
   if (out_dtype == CSN_BF16) {
     if (two) gemm_nt_bf16_kernel<bf16_t, 2><<<grid, 256, 65536, st>>>((const bf16_t*)A, (const bf16_t*)Bt, bias, (bf16_t*)C, M, N, K, 0);
@@ -412,7 +431,7 @@ int launch_gemm_tn_slabs(const void* A, const void* B, float* slabs, int64_t M, 
                     ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15) == 0 &&
                     getenv("CSN_GEMM_GENERIC") == nullptr;
   if (fast) {
-    dim3 grid((unsigned)((N + 127) / 128), (unsigned)((M + 127) / 128), (unsigned)S);
+    dim3 grid((unsigned)(((N + 127) / 128) * ((M + 127) / 128) * S));
     if (getenv("CSN_TN_NO_TR"))
       gemm_tn_bf16_kernel<false><<<grid, 256, 0, st>>>((const bf16_t*)A, (const bf16_t*)B, slabs, M, N, K, kper);
     else
