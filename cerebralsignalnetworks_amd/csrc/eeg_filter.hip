@@ -95,6 +95,177 @@ __global__ void __launch_bounds__(64) eeg_filter_rows_kernel(const float* __rest
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// v2 kernel ("scan"): the time recurrence is parallelised, so the kernel is HBM-bound instead of
+// bound by one lane walking 500 dependent steps.
+//   A workgroup takes 16 consecutive rows (channels) and cuts each into 16 chunks of 32 samples;
+//   thread (row, chunk) filters its chunk from a ZERO state (float64), giving the zero-state
+//   response and the chunk's end state.  The cascade is linear, so the true output is
+//       y[n] = y_zero_state[n] + sum_i s0_i * phi_i[n],   s0(chunk k+1) = A^32 s0(chunk k) + end_k
+//   with phi_i = response to a unit initial state component and A^32 the 32-step state transition --
+//   both produced once per call by a tiny basis kernel.  Row statistics come from the corrected
+//   chunks; everything stays in LDS between the coalesced load (16 rows are one contiguous 32 KB
+//   run of x) and the transposed, channel-fastest store.
+// LDS: 16 x 546 floats (chunk stride 33, row stride 546 = 2 mod 32: conflict-free for the
+// per-chunk walk AND for the transposed read of the store phase) + end states + statistics.
+// ---------------------------------------------------------------------------------------------
+static constexpr int kScanRows = 16, kScanChunks = 16, kScanLen = 32, kScanRS = 546;
+
+struct ScanBasis {
+  double phi[16][kScanLen];   // [state component][n]
+  double apow[16][16];        // [j][i] = component j of the state after kScanLen steps from e_i
+};
+
+template <int NSEC>
+__global__ void __launch_bounds__(64) eeg_filter_basis_kernel(SosParams p, ScanBasis* out) {
+  const int i = threadIdx.x;
+  if (i >= 2 * NSEC) return;
+  double s1[8], s2[8];
+#pragma unroll
+  for (int s = 0; s < 8; ++s) { s1[s] = 0.0; s2[s] = 0.0; }
+#pragma unroll
+  for (int s = 0; s < NSEC; ++s) {
+    if (i == 2 * s) s1[s] = 1.0;
+    if (i == 2 * s + 1) s2[s] = 1.0;
+  }
+  for (int n = 0; n < kScanLen; ++n) out->phi[i][n] = biquad_cascade<NSEC>(0.0, p, s1, s2);
+#pragma unroll
+  for (int s = 0; s < NSEC; ++s) {
+    out->apow[2 * s][i] = s1[s];
+    out->apow[2 * s + 1][i] = s2[s];
+  }
+}
+
+template <int NSEC, typename OutT>
+__global__ void __launch_bounds__(256)
+eeg_filter_scan_kernel(const float* __restrict__ x, OutT* __restrict__ y, int B, int C, int T, SosParams p,
+                       const ScanBasis* __restrict__ basis, int ddof, int time_major) {
+  constexpr int NS = 2 * NSEC > 0 ? 2 * NSEC : 1;
+  __shared__ float xs[kScanRows * kScanRS];
+  __shared__ double ez[kScanRows][kScanChunks][NS];
+  __shared__ double st[kScanRows][kScanChunks][2];
+  __shared__ double phi_s[NS][kScanLen];
+  __shared__ double apow_s[NS][NS];
+  const int tid = threadIdx.x;
+  const int64_t rows_total = (int64_t)B * C;
+  const int64_t row0 = (int64_t)blockIdx.x * kScanRows;
+  const int nrows = (int)((rows_total - row0 < kScanRows) ? rows_total - row0 : kScanRows);
+
+  // ---- phase 1: coalesced load of nrows x T floats (one contiguous run of x) into the skewed tile
+  {
+    const float* src = x + row0 * (int64_t)T;
+    const int total = nrows * T;
+    if ((T & 3) == 0) {
+      for (int e = tid * 4; e < total; e += 256 * 4) {
+        const float4 v = *reinterpret_cast<const float4*>(src + e);
+        const int r = e / T, t = e - r * T;
+        float* d = xs + r * kScanRS + (t >> 5) * 33 + (t & 31);
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+      }
+    } else {
+      for (int e = tid; e < total; e += 256) {
+        const int r = e / T, t = e - r * T;
+        xs[r * kScanRS + (t >> 5) * 33 + (t & 31)] = src[e];
+      }
+    }
+    for (int e = tid; e < NS * kScanLen; e += 256) phi_s[e / kScanLen][e % kScanLen] = basis->phi[e / kScanLen][e % kScanLen];
+    for (int e = tid; e < NS * NS; e += 256) apow_s[e / NS][e % NS] = basis->apow[e / NS][e % NS];
+  }
+  __syncthreads();
+
+  // ---- phase 2: zero-state response of chunk k of row r, in place
+  const int r = tid & 15, k = tid >> 4;
+  const int t_beg = k * kScanLen;
+  const int len = (t_beg >= T) ? 0 : ((T - t_beg < kScanLen) ? T - t_beg : kScanLen);
+  float* mine = xs + r * kScanRS + k * 33;
+  {
+    double s1[8], s2[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) { s1[s] = 0.0; s2[s] = 0.0; }
+    if (r < nrows)
+      for (int j = 0; j < len; ++j) mine[j] = (float)biquad_cascade<NSEC>((double)mine[j], p, s1, s2);
+#pragma unroll
+    for (int s = 0; s < NSEC; ++s) {
+      ez[r][k][2 * s] = s1[s];
+      ez[r][k][2 * s + 1] = s2[s];
+    }
+  }
+  __syncthreads();
+
+  // ---- phase 3: true initial state of this chunk = fold of the earlier chunks' end states
+  double s0[NS];
+#pragma unroll
+  for (int i = 0; i < NS; ++i) s0[i] = 0.0;
+  for (int kk = 0; kk < k; ++kk) {
+    double nx[NS];
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+      double a = ez[r][kk][j];
+#pragma unroll
+      for (int i = 0; i < NS; ++i) a = fma(apow_s[j][i], s0[i], a);
+      nx[j] = a;
+    }
+#pragma unroll
+    for (int j = 0; j < NS; ++j) s0[j] = nx[j];
+  }
+
+  // ---- phase 4: add the homogeneous response, accumulate the row statistics
+  double sum = 0.0, sumsq = 0.0;
+  if (r < nrows)
+    for (int j = 0; j < len; ++j) {
+      double v = (double)mine[j];
+#pragma unroll
+      for (int i = 0; i < (NSEC > 0 ? NS : 0); ++i) v = fma(s0[i], phi_s[i][j], v);
+      sum += v;
+      sumsq = fma(v, v, sumsq);
+      mine[j] = (float)v;
+    }
+  st[r][k][0] = sum;
+  st[r][k][1] = sumsq;
+  __syncthreads();
+
+  // ---- phase 5: normalise and store channel-fastest: lane = (channel c, time phase tq)
+  const int c = tid & 15, tq = tid >> 4;
+  if (c >= nrows) return;
+  double tsum = 0.0, tsq = 0.0;
+#pragma unroll
+  for (int kk = 0; kk < kScanChunks; ++kk) { tsum += st[c][kk][0]; tsq += st[c][kk][1]; }
+  const double mean = tsum / (double)T;
+  const double inv = 1.0 / sqrt((tsq - tsum * mean) / (double)(T - ddof));
+  const float meanf = (float)mean, invf = (float)inv;
+  const int64_t row = row0 + c;
+  const int b = (int)(row / C), ch = (int)(row % C);
+  const int64_t t_stride = time_major ? (int64_t)B * C : (int64_t)C;
+  OutT* yo = y + (time_major ? (int64_t)b * C + ch : ((int64_t)b * T) * C + ch);
+  const float* src = xs + c * kScanRS;
+  for (int t = tq; t < T; t += 16) {
+    const double v = ((double)src[(t >> 5) * 33 + (t & 31)] - mean) * inv;
+    yo[(int64_t)t * t_stride] = from_f32<OutT>((float)v);
+  }
+  (void)meanf; (void)invf;
+}
+
+static ScanBasis* g_basis[16] = {nullptr};
+
+template <int NSEC>
+static int launch_scan(const float* x, void* y, int B, int C, int T, const SosParams& p, int ddof, int out_dtype,
+                       int time_major, hipStream_t st) {
+  int dev = 0;
+  CSN_HIP_CHECK(hipGetDevice(&dev));
+  CSN_REQUIRE(dev >= 0 && dev < 16, "device index %d out of range", dev);
+  if (g_basis[dev] == nullptr) CSN_HIP_CHECK(hipMalloc((void**)&g_basis[dev], sizeof(ScanBasis)));
+  eeg_filter_basis_kernel<NSEC><<<1, 64, 0, st>>>(p, g_basis[dev]);
+  CSN_LAUNCH_CHECK();
+  const int64_t rows = (int64_t)B * C;
+  const unsigned grid = (unsigned)((rows + kScanRows - 1) / kScanRows);
+  if (out_dtype == CSN_BF16)
+    eeg_filter_scan_kernel<NSEC, bf16_t><<<grid, 256, 0, st>>>(x, (bf16_t*)y, B, C, T, p, g_basis[dev], ddof, time_major);
+  else
+    eeg_filter_scan_kernel<NSEC, float><<<grid, 256, 0, st>>>(x, (float*)y, B, C, T, p, g_basis[dev], ddof, time_major);
+  CSN_LAUNCH_CHECK();
+  return CSN_OK;
+}
+
 template <int NSEC>
 static int launch_rows(const float* x, void* y, int B, int C, int T, const SosParams& p, int ddof, int out_dtype,
                        int time_major, hipStream_t st) {
@@ -133,6 +304,16 @@ extern "C" int csn_eeg_bandpass_znorm(const float* x, int B, int C, int T, const
     p.c[s][4] = sos[s * 6 + 5] / a0;
   }
   hipStream_t st = as_stream(stream);
+  if (T <= kScanChunks * kScanLen && nsec <= 5 && getenv("CSN_FILTER_V1") == nullptr) {
+    switch (nsec) {
+      case 0: return launch_scan<0>(x, y, B, C, T, p, ddof, out_dtype, time_major, st);
+      case 1: return launch_scan<1>(x, y, B, C, T, p, ddof, out_dtype, time_major, st);
+      case 2: return launch_scan<2>(x, y, B, C, T, p, ddof, out_dtype, time_major, st);
+      case 3: return launch_scan<3>(x, y, B, C, T, p, ddof, out_dtype, time_major, st);
+      case 4: return launch_scan<4>(x, y, B, C, T, p, ddof, out_dtype, time_major, st);
+      default: return launch_scan<5>(x, y, B, C, T, p, ddof, out_dtype, time_major, st);
+    }
+  }
   switch (nsec) {
     case 0: return launch_rows<0>(x, y, B, C, T, p, ddof, out_dtype, time_major, st);
     case 1: return launch_rows<1>(x, y, B, C, T, p, ddof, out_dtype, time_major, st);

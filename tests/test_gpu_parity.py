@@ -416,7 +416,10 @@ def _rel(a, b):
 
 
 @pytest.mark.parametrize("B,T,C,H,L,chunk", [(70, 75, 24, 128, 2, "32"), (33, 40, 16, 128, 3, "8"),
-                                             (64, 20, 32, 256, 1, "32"), (5, 9, 8, 384, 2, "4")])
+                                             (64, 20, 32, 256, 1, "32"), (5, 9, 8, 384, 2, "4"),
+                                             (6, 44, 128, 1024, 2, "16"),      # cfg4 width (Spampinato split: H=1024)
+                                             (40, 24, 128, 128, 4, "8"),       # 4 layers (TrainSpampinato.py:368)
+                                             (130, 33, 16, 512, 2, "32")])
 def test_fast_path_matches_oracle_and_v1(cuda, B, T, C, H, L, chunk):
     rng = np.random.default_rng(B * T + H)
     p = lstm.init_params(C, H, L, 8, None, seed=5)
