@@ -56,7 +56,7 @@ def build_parser():
     p.add_argument('--hidden_size', type=int, default=96, help='lstm_size (reference call site: 96)')
     p.add_argument('--lstm_layers', type=int, default=2)
     p.add_argument('--output_size', type=int, default=384)
-    p.add_argument('--loss', type=str, default="featdist", choices=["featdist", "cosine", "kd"])
+    p.add_argument('--loss', type=str, default="featdist", choices=["featdist", "cosine", "kd", "barlow"])
     p.add_argument('--dtype', type=str, default="bf16", choices=["bf16", "f32"])
     p.add_argument('--fs', type=float, default=1000.0, help='sampling rate for the band-pass design')
     p.add_argument('--filter_order', type=int, default=3, choices=[0, 3, 4, 5], help='0 = no band-pass')

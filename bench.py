@@ -138,12 +138,20 @@ def main():
             pr = cabi.lstm_profile_read()
             peak = MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else 157.3
             us = {k: (1e3 * pr[k + "_ms"] / max(1, pr[k + "_launches"])) for k in ("fwd", "bwd")}
-            dom = "bwd" if us["bwd"] >= us["fwd"] else "fwd"
+            dom = "bwd" if pr["bwd_ms"] >= pr["fwd_ms"] else "fwd"      # largest total time in the step
             cells_per_launch = pr[dom + "_cells"] / max(1, pr[dom + "_launches"])
             flops_per_launch = 2.0 * B * 4 * H * H * cells_per_launch     # one recurrent product per cell problem
             ach = flops_per_launch / (us[dom] * 1e-6) / 1e12
-            res["roofline"] = {"bound": "mfma", "kernel": f"lstm_cell_{dom}_il_kernel", "achieved": ach, "peak": peak,
-                               "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
+            kname = "lstm_cell_bwd_il_kernel" if dom == "bwd" else (
+                "lstm_fwd_persist_kernel" if pr["fwd_launches"] < T else "lstm_cell_fwd_il_kernel")
+            traffic = None      # HBM bytes per launch from the committed PMC passes (profiles/), same workload
+            try:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+                traffic = pmc["kernels"][kname]["hbm_bytes_per_launch_corrected"]
+            except (OSError, KeyError, ValueError):
+                pass
+            res["roofline"] = {"bound": "mfma", "kernel": kname, "achieved": ach, "peak": peak,
+                               "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,
                                "us_per_launch": us, "launches": {k: pr[k + "_launches"] for k in ("fwd", "bwd")},
                                "cells_per_launch": cells_per_launch, "flops_per_launch": flops_per_launch,
                                "note": "per-timestep recurrent GEMM; limited by operand loads at the per-CU L2 rate "

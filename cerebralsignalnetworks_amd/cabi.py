@@ -11,7 +11,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libcsn_hip.so")
+LIB_PATH = os.environ.get("CSN_LIB_PATH") or os.path.join(_HERE, "lib", "libcsn_hip.so")
 
 CSN_F32, CSN_BF16 = 0, 1
 ABI_VERSION = 1
@@ -32,6 +32,9 @@ SIGNATURES = {
     "csn_target_arch": (ctypes.c_char_p, []),
     "csn_eeg_bandpass_znorm": (_c_int, [_c_void_p, _c_int, _c_int, _c_int, ctypes.POINTER(ctypes.c_double), _c_int,
                                         _c_int, _c_void_p, _c_int, _c_int, _c_void_p]),
+    "csn_eeg_filtfilt_scratch_bytes": (_c_size_t, [_c_int, _c_int, _c_int, _c_int]),
+    "csn_eeg_filtfilt": (_c_int, [_c_void_p, _c_int, _c_int, _c_int, ctypes.POINTER(ctypes.c_double), _c_int,
+                                  _c_void_p, _c_void_p, _c_void_p]),
     "csn_lstm_workspace_bytes": (_c_size_t, [ctypes.POINTER(LstmDesc), _c_int]),
     "csn_lstm_forward": (_c_int, [ctypes.POINTER(LstmDesc), _c_void_p, _c_i64, _c_i64,
                                   ctypes.POINTER(_c_void_p), ctypes.POINTER(_c_void_p),
@@ -130,6 +133,22 @@ def eeg_bandpass_znorm(x_bct, sos, ddof=0, out_dtype=torch.float32, time_major=F
     y = torch.empty((T, B, C) if time_major else (B, T, C), dtype=out_dtype, device=x.device)
     _check(load().csn_eeg_bandpass_znorm(_ptr(x), B, C, T, sos.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
                                          sos.shape[0], int(ddof), _ptr(y), _dt(out_dtype), int(time_major), _stream()))
+    return y
+
+
+def eeg_filtfilt(x_stc, sos):
+    """Zero-phase band-pass of eeg[S,T,C] float32 (device); sos = [nsec,6] host array."""
+    import numpy as np
+    _need_cuda(x_stc)
+    x = x_stc.float().contiguous()
+    S, T, C = x.shape
+    sos = np.ascontiguousarray(np.asarray(sos, dtype=np.float64).reshape(-1, 6))
+    lib = load()
+    scratch = torch.empty(max(1, lib.csn_eeg_filtfilt_scratch_bytes(S, T, C, sos.shape[0])), dtype=torch.uint8,
+                          device=x.device)
+    y = torch.empty_like(x)
+    _check(lib.csn_eeg_filtfilt(_ptr(x), S, T, C, sos.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), sos.shape[0],
+                                _ptr(y), _ptr(scratch), _stream()))
     return y
 
 

@@ -279,6 +279,73 @@ static int launch_rows(const float* x, void* y, int B, int C, int T, const SosPa
   return CSN_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// zero-phase variant: forward-backward filtering with odd extension and steady-state initial
+// conditions -- scipy.signal.filtfilt as applied by Utilities.remove_noise
+// (/root/reference/utils/Utilities.py:411-428), evaluated on the biquad cascade in float64.
+// Layout [S][T][C] (channels fastest, as remove_noise takes it): lanes = channels, so every load and
+// store of a time step is a coalesced run.  The forward pass writes its float64 output to scratch
+// [n][row]; the backward pass reads it in reverse, restarts the cascade at steady state for its first
+// sample and writes the un-padded samples.
+// ---------------------------------------------------------------------------------------------
+struct ZiParams {
+  double s1[8], s2[8];   // steady-state DF2T state of each section per unit of the CASCADE input
+};
+
+template <int NSEC>
+__global__ void __launch_bounds__(64)
+eeg_filtfilt_kernel(const float* __restrict__ x, float* __restrict__ y, double* __restrict__ scratch, int S, int T,
+                    int C, int pad, SosParams p, ZiParams zi) {
+  const int64_t row = (int64_t)blockIdx.x * 64 + threadIdx.x;      // (segment, channel)
+  const int64_t rows = (int64_t)S * C;
+  if (row >= rows) return;
+  const int sgm = (int)(row / C), c = (int)(row % C);
+  const float* xr = x + (int64_t)sgm * T * C + c;                  // element t at xr[t*C]
+  float* yr = y + (int64_t)sgm * T * C + c;
+  const int N = T + 2 * pad;
+  auto ext = [&](int n) -> double {                                // odd extension about both ends
+    if (n < pad) return 2.0 * (double)xr[0] - (double)xr[(int64_t)(pad - n) * C];
+    if (n >= pad + T) return 2.0 * (double)xr[(int64_t)(T - 1) * C] - (double)xr[(int64_t)(2 * T + pad - 2 - n) * C];
+    return (double)xr[(int64_t)(n - pad) * C];
+  };
+  double s1[8], s2[8];
+  const double x0 = ext(0);
+#pragma unroll
+  for (int s = 0; s < 8; ++s) { s1[s] = zi.s1[s] * x0; s2[s] = zi.s2[s] * x0; }
+  for (int n = 0; n < N; ++n) scratch[(int64_t)n * rows + row] = biquad_cascade<NSEC>(ext(n), p, s1, s2);
+  const double y0 = scratch[(int64_t)(N - 1) * rows + row];
+#pragma unroll
+  for (int s = 0; s < 8; ++s) { s1[s] = zi.s1[s] * y0; s2[s] = zi.s2[s] * y0; }
+  for (int n = N - 1; n >= 0; --n) {
+    const double v = biquad_cascade<NSEC>(scratch[(int64_t)n * rows + row], p, s1, s2);
+    if (n >= pad && n < pad + T) yr[(int64_t)(n - pad) * C] = (float)v;
+  }
+}
+
+template <int NSEC>
+static int launch_filtfilt(const float* x, float* y, double* scratch, int S, int T, int C, int pad, const SosParams& p,
+                           const ZiParams& zi, hipStream_t st) {
+  const int64_t rows = (int64_t)S * C;
+  eeg_filtfilt_kernel<NSEC><<<(unsigned)((rows + 63) / 64), 64, 0, st>>>(x, y, scratch, S, T, C, pad, p, zi);
+  CSN_LAUNCH_CHECK();
+  return CSN_OK;
+}
+
+static int fill_sos(const double* sos, int nsec, SosParams* p, const char* fn) {
+  for (int s = 0; s < 8; ++s)
+    for (int k = 0; k < 5; ++k) p->c[s][k] = 0.0;
+  for (int s = 0; s < nsec; ++s) {
+    const double a0 = sos[s * 6 + 3];
+    CSN_REQUIRE(a0 != 0.0, "%s: section %d has a0 == 0", fn, s);
+    p->c[s][0] = sos[s * 6 + 0] / a0;
+    p->c[s][1] = sos[s * 6 + 1] / a0;
+    p->c[s][2] = sos[s * 6 + 2] / a0;
+    p->c[s][3] = sos[s * 6 + 4] / a0;
+    p->c[s][4] = sos[s * 6 + 5] / a0;
+  }
+  return CSN_OK;
+}
+
 }  // namespace csn
 
 extern "C" int csn_eeg_bandpass_znorm(const float* x, int B, int C, int T, const double* sos, int nsec, int ddof,
@@ -324,5 +391,46 @@ extern "C" int csn_eeg_bandpass_znorm(const float* x, int B, int C, int T, const
     case 6: return launch_rows<6>(x, y, B, C, T, p, ddof, out_dtype, time_major, st);
     case 7: return launch_rows<7>(x, y, B, C, T, p, ddof, out_dtype, time_major, st);
     default: return launch_rows<8>(x, y, B, C, T, p, ddof, out_dtype, time_major, st);
+  }
+}
+
+extern "C" size_t csn_eeg_filtfilt_scratch_bytes(int S, int T, int C, int nsec) {
+  if (S <= 0 || T <= 0 || C <= 0 || nsec <= 0) return 0;
+  const int pad = 3 * (2 * nsec + 1);
+  return (size_t)(T + 2 * pad) * (size_t)S * (size_t)C * sizeof(double);
+}
+
+extern "C" int csn_eeg_filtfilt(const float* x, int S, int T, int C, const double* sos, int nsec, float* y,
+                                void* scratch, csnStream_t stream) {
+  using namespace csn;
+  CSN_REQUIRE(x && y && sos && scratch, "csn_eeg_filtfilt: null pointer");
+  CSN_REQUIRE(nsec >= 1 && nsec <= 8, "csn_eeg_filtfilt: nsec=%d outside 1..8", nsec);
+  const int pad = 3 * (2 * nsec + 1);        // scipy filtfilt default: 3 * max(len(a), len(b))
+  CSN_REQUIRE(S > 0 && C > 0 && T > pad, "csn_eeg_filtfilt: T=%d must exceed padlen=%d", T, pad);
+  SosParams p;
+  if (int rc = fill_sos(sos, nsec, &p, "csn_eeg_filtfilt")) return rc;
+  // steady state of each DF2T section for a constant cascade input of 1 (sosfilt_zi):
+  // y = G u, s1 = (G - b0) u, s2 = (b2 - a2 G) u, and the next section sees u' = G u
+  ZiParams zi;
+  double u = 1.0;
+  for (int s = 0; s < 8; ++s) zi.s1[s] = zi.s2[s] = 0.0;
+  for (int s = 0; s < nsec; ++s) {
+    const double b0 = p.c[s][0], b1 = p.c[s][1], b2 = p.c[s][2], a1 = p.c[s][3], a2 = p.c[s][4];
+    const double G = (b0 + b1 + b2) / (1.0 + a1 + a2);
+    zi.s1[s] = (G - b0) * u;
+    zi.s2[s] = (b2 - a2 * G) * u;
+    u *= G;
+  }
+  hipStream_t st = as_stream(stream);
+  double* sc = (double*)scratch;
+  switch (nsec) {
+    case 1: return launch_filtfilt<1>(x, y, sc, S, T, C, pad, p, zi, st);
+    case 2: return launch_filtfilt<2>(x, y, sc, S, T, C, pad, p, zi, st);
+    case 3: return launch_filtfilt<3>(x, y, sc, S, T, C, pad, p, zi, st);
+    case 4: return launch_filtfilt<4>(x, y, sc, S, T, C, pad, p, zi, st);
+    case 5: return launch_filtfilt<5>(x, y, sc, S, T, C, pad, p, zi, st);
+    case 6: return launch_filtfilt<6>(x, y, sc, S, T, C, pad, p, zi, st);
+    case 7: return launch_filtfilt<7>(x, y, sc, S, T, C, pad, p, zi, st);
+    default: return launch_filtfilt<8>(x, y, sc, S, T, C, pad, p, zi, st);
   }
 }

@@ -252,3 +252,13 @@ int launch_fwd_persist(const PersistFwdArgs& a, hipStream_t st) {
 }
 
 }  // namespace csn
+
+#ifdef CSN_PSTAMPS
+// diagnostic build only (make diag): read and clear the per-phase tick sums
+extern "C" int csn_debug_read_pstamps(unsigned long long* out) {
+  unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pstamps), sizeof(z)) != hipSuccess) return 1;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_pstamps), z, sizeof(z)) != hipSuccess) return 1;
+  return 0;
+}
+#endif

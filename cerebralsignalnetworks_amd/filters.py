@@ -40,3 +40,11 @@ class EEGFilters:
 
 def eeg_bandpass_znorm(eeg_bct, sos, ddof=0, out_dtype=torch.float32, time_major=False):
     return cabi.eeg_bandpass_znorm(eeg_bct, sos, ddof=ddof, out_dtype=out_dtype, time_major=time_major)
+
+
+def remove_noise(eeg_data, sampling_rate):
+    """``Utilities.remove_noise`` (/root/reference/utils/Utilities.py:411-428) on the GPU: Butterworth order 4,
+    1-50 Hz, zero-phase (forward-backward) filtering of eeg[S,T,C]; returns a tensor of the same shape."""
+    nyquist_freq = 0.5 * sampling_rate
+    sos = butter(4, [1.0 / nyquist_freq, 50.0 / nyquist_freq], btype='band', output='sos')
+    return cabi.eeg_filtfilt(eeg_data, sos)

@@ -120,3 +120,53 @@ class _AllReduceSum(torch.autograd.Function):
         g = g.clone()
         torch.distributed.all_reduce(g)
         return g
+
+
+class LARS(torch.optim.Optimizer):
+    """LARS of /root/reference/EEG-BarlowNetworks/optim.py:5-44 (bias/norm exclusion = ``ndim == 1``)."""
+
+    def __init__(self, params, lr, weight_decay=0, momentum=0.9, eta=0.001, weight_decay_filter=False,
+                 lars_adaptation_filter=False):
+        defaults = dict(lr=lr, weight_decay=weight_decay, momentum=momentum, eta=eta,
+                        weight_decay_filter=weight_decay_filter, lars_adaptation_filter=lars_adaptation_filter)
+        super().__init__(params, defaults)
+
+    @staticmethod
+    def exclude_bias_and_norm(p):
+        return p.ndim == 1
+
+    @torch.no_grad()
+    def step(self):
+        for g in self.param_groups:
+            for p in g['params']:
+                dp = p.grad
+                if dp is None:
+                    continue
+                if not g['weight_decay_filter'] or not self.exclude_bias_and_norm(p):
+                    dp = dp.add(p, alpha=g['weight_decay'])
+                if not g['lars_adaptation_filter'] or not self.exclude_bias_and_norm(p):
+                    param_norm, update_norm = torch.norm(p), torch.norm(dp)
+                    one = torch.ones_like(param_norm)
+                    q = torch.where(param_norm > 0., torch.where(update_norm > 0, (g['eta'] * param_norm / update_norm), one), one)
+                    dp = dp.mul(q)
+                state = self.state[p]
+                if 'mu' not in state:
+                    state['mu'] = torch.zeros_like(p)
+                mu = state['mu']
+                mu.mul_(g['momentum']).add_(dp)
+                p.add_(mu, alpha=-g['lr'])
+
+
+def barlow_learning_rate(step, epochs, steps_per_epoch, batch_size):
+    """adjust_learning_rate of EEG-BarlowNetworks/barlow_utils.py:8-21 (un-weighted lr)."""
+    import math
+    max_steps = epochs * steps_per_epoch
+    warmup_steps = 10 * steps_per_epoch
+    base_lr = batch_size / 256
+    if step < warmup_steps:
+        return base_lr * step / warmup_steps
+    step -= warmup_steps
+    max_steps -= warmup_steps
+    q = 0.5 * (1 + math.cos(math.pi * step / max_steps))
+    end_lr = base_lr * 0.001
+    return base_lr * q + end_lr * (1 - q)

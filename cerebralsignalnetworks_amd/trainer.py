@@ -19,7 +19,8 @@ import torch.distributed as dist
 import torch.nn as nn
 
 from . import filters
-from .losses import CosineSimilarityLoss, FeatureDistributionLoss, HyperParams, loss_fn_kd
+from .losses import (CosineSimilarityLoss, FeatureDistributionLoss, HyperParams, loss_fn_kd, BarlowTwinsLoss,
+                     LARS)
 
 
 def dist_info():
@@ -79,12 +80,15 @@ class DistillTrainer:
             self.opt = torch.optim.AdamW(params, lr=lr)
         elif optimizer == "adam":       # LSTMDistill.py:322
             self.opt = torch.optim.Adam(params, lr=lr)
+        elif optimizer == "lars":       # EEG-BarlowNetworks/train.py (weights + biases groups collapsed)
+            self.opt = LARS(params, lr=lr, weight_decay=1e-6, weight_decay_filter=True, lars_adaptation_filter=True)
         else:
             raise ValueError(optimizer)
         self.cosine = CosineSimilarityLoss()
         self.featdist = FeatureDistributionLoss(nepochs, HyperParams.warmup_teacher_temp, HyperParams.teacher_temp,
                                                 HyperParams.warmup_teacher_temp_epochs)
         self.kd_params = kd_params
+        self.barlow = None
         rank, world = dist_info()
         if world > 1:   # identical initial weights on every rank
             for p in model.parameters():
@@ -106,6 +110,14 @@ class DistillTrainer:
         if self.loss_name == "kd":
             feat = out[0] if isinstance(out, tuple) else out
             return loss_fn_kd(feat, labels, targets, self.kd_params)
+        if self.loss_name == "barlow":
+            # BASELINE.json config 5: Barlow-Twins cross-correlation between the LSTM embedding of the EEG view
+            # and the (frozen) image embedding; net.py:33-42 with the global batch size and an all-reduced c
+            feat = out[0] if isinstance(out, tuple) else out
+            if self.barlow is None:
+                _, world = dist_info()
+                self.barlow = BarlowTwinsLoss(feat.shape[1], feat.shape[0] * world).to(feat.device)
+            return self.barlow(feat, targets)
         raise ValueError(self.loss_name)
 
     def train_step(self, eeg_bct, targets, labels=None, epoch=0):

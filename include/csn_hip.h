@@ -59,6 +59,16 @@ int csn_eeg_bandpass_znorm(const float* x, int B, int C, int T,
                            const double* sos, int nsec, int ddof,
                            void* y, int out_dtype, int time_major, csnStream_t stream);
 
+/* Zero-phase variant.  Replaces: signal.filtfilt(b, a, eeg[s, :, c]) for every (s, c) in
+ * Utilities.remove_noise, utils/Utilities.py:411-428 (Butterworth order 4, 1-50 Hz; scipy defaults:
+ * odd extension, padlen = 3*max(len(a),len(b)) = 3*(2*nsec+1), steady-state initial conditions),
+ * evaluated on the second-order-section cascade in float64.
+ *   x, y    [S,T,C] float32 (samples x time x channels, the layout remove_noise takes), T > padlen
+ *   scratch csn_eeg_filtfilt_scratch_bytes(S,T,C,nsec) bytes of device memory */
+size_t csn_eeg_filtfilt_scratch_bytes(int S, int T, int C, int nsec);
+int csn_eeg_filtfilt(const float* x, int S, int T, int C, const double* sos, int nsec,
+                     float* y, void* scratch, csnStream_t stream);
+
 /* ------------------------------------------------------------------------------------
  * K3  stacked LSTM, zero initial state, gate order i,f,g,o, nn.LSTM parameter layout.
  * Replaces: nn.LSTM(input, hidden, num_layers, batch_first=True) forward/backward at

@@ -515,3 +515,39 @@ def test_featdist_and_kd_losses_train_on_gpu(cuda):
     loss2 = tr2.train_step(dev_t(x, cuda), dev_t(teacher, cuda), dev_t(lab, cuda))
     feat2 = lstm.model_forward(eeg_filter.eeg_bandpass_znorm(x, np.zeros((0, 6))), p2, 1)
     assert abs(loss2.item() - losses.loss_fn_kd(feat2, lab, teacher, 0.5, 4.0)) < 1e-4
+
+
+def test_barlow_training_step_on_lstm_embeddings(cuda):
+    """BASELINE.json configs[4] shape of the loss: Barlow-Twins on LSTM embeddings, HIP off-diagonal reduction,
+    LARS step -- loss vs the oracle restatement of net.py:33-42."""
+    from cerebralsignalnetworks_amd.trainer import DistillTrainer
+    rng = np.random.default_rng(6)
+    B, C, T, H, D = 32, 16, 24, 64, 48
+    x = rng.standard_normal((B, C, T)).astype(np.float32)
+    tgt = rng.standard_normal((B, D)).astype(np.float32)
+    m = Model(input_size=C, lstm_size=H, lstm_layers=1, output_size=D, include_top=False,
+              compute_dtype=torch.float32).to(cuda)
+    p = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
+    tr = DistillTrainer(m, None, loss="barlow", optimizer="lars", lr=0.1)
+    loss = tr.train_step(dev_t(x, cuda), dev_t(tgt, cuda))
+    feat = lstm.model_forward(eeg_filter.eeg_bandpass_znorm(x, np.zeros((0, 6))), p, 1)
+    want, _ = losses.barlow_loss(feat, tgt, B)
+    assert abs(loss.item() - want) < 1e-3 * want
+    moved = (m.fc.weight.detach().cpu().numpy() != p["fc.weight"]).mean()
+    assert moved > 0.99
+
+
+def test_zero_phase_filtfilt_matches_scipy_golden(cuda, golden):
+    """Utilities.remove_noise (butter-4, 1-50 Hz, filtfilt) on [S,T,C].  The (b,a) polynomial form scipy
+    evaluates is ill-conditioned (two float64 evaluations differ at 5e-5, see test_oracle); the device
+    evaluates the same filter as a float64 biquad cascade, so agreement is held to 2e-4."""
+    from cerebralsignalnetworks_amd import remove_noise
+    g = golden("filter_apply.npz")
+    x = g["filtfilt_x"].astype(np.float32)                       # [2,500,8]
+    y = remove_noise(dev_t(x, cuda), 1000).cpu().numpy()
+    np.testing.assert_allclose(y, g["filtfilt_y"], atol=2e-4)
+    want = eeg_filter.remove_noise(x, 1000)                      # oracle on the float32-rounded input
+    np.testing.assert_allclose(y, want, atol=2e-4)
+    # linearity (size-independent property): filtfilt(2.5 x) == 2.5 filtfilt(x)
+    y2 = remove_noise(dev_t(2.5 * x, cuda), 1000).cpu().numpy()
+    np.testing.assert_allclose(y2, 2.5 * y, atol=1e-5)

@@ -136,3 +136,20 @@ def test_retrieval_known_answers():
     # query0 top3 = dog,dog,cat -> hit, 2 instances; query1 top3 = cat,cat,dog -> hit, 1 instance
     assert per["dog"]["TP"] == 2 and per["dog"]["classIntanceRetrival"] == 3
     assert rec == 100.0 and prec == round(300 / 6, 2) and top1 == 0.5
+
+
+def test_product_lars_and_lr_schedule_match_oracle(golden):
+    """Host-side mirrors (pure torch, no kernels): LARS and the Barlow LR schedule."""
+    import torch
+    from cerebralsignalnetworks_amd.losses import LARS, barlow_learning_rate
+    g = golden("losses.npz")
+    w = torch.from_numpy(g["lars_w0"].copy()).requires_grad_(True)
+    b = torch.from_numpy(g["lars_b0"].copy()).requires_grad_(True)
+    opt = LARS([w, b], lr=0.2, weight_decay=1e-3, weight_decay_filter=True, lars_adaptation_filter=True)
+    for it in range(2):
+        w.grad, b.grad = torch.from_numpy(g["lars_gw"]).clone(), torch.from_numpy(g["lars_gb"]).clone()
+        opt.step()
+        np.testing.assert_allclose(w.detach().numpy(), g[f"lars_w{it + 1}"], atol=1e-14)
+        np.testing.assert_allclose(b.detach().numpy(), g[f"lars_b{it + 1}"], atol=1e-14)
+    for s in (0, 7, 50, 73, 99):
+        assert barlow_learning_rate(s, 20, 5, 512) == losses.barlow_lr(s, 20, 5, 512)

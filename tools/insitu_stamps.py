@@ -1,0 +1,24 @@
+"""Diagnostic: phase breakdown of the persistent forward INSIDE a real training step (diag library)."""
+import ctypes, os, sys
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ["CSN_LIB_PATH"] = os.path.join(ROOT, "cerebralsignalnetworks_amd", "lib", "libcsn_hip_diag.so")
+from cerebralsignalnetworks_amd import cabi, Model, EEGFilters  # noqa: E402
+from cerebralsignalnetworks_amd.trainer import DistillTrainer  # noqa: E402
+
+dev = torch.device("cuda:0")
+B, C, T, H, L, D = 256, 128, 500, 768, 2, 384
+m = Model(input_size=C, lstm_size=H, lstm_layers=L, output_size=D, include_top=False).to(dev)
+tr = DistillTrainer(m, EEGFilters(1000, 3).sos, loss="cosine")
+x = torch.randn(B, C, T, device=dev); tg = torch.randn(B, D, device=dev)
+lib = cabi.load()
+lib.csn_debug_read_pstamps.argtypes = [ctypes.POINTER(ctypes.c_ulonglong)]
+buf = (ctypes.c_ulonglong * 8)()
+for it in range(4):
+    tr.train_step(x, tg)
+    torch.cuda.synchronize()
+    lib.csn_debug_read_pstamps(buf)
+    per = [buf[i] * 0.01 / (T * L) for i in range(6)]
+    print("step %d per-layer-step us: wait %.2f | loads+mfma %.2f | lds %.2f | epilogue %.2f | drain %.2f | signal %.2f | sum %.2f"
+          % (it, *per, sum(per)), flush=True)
