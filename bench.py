@@ -65,10 +65,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("CSN_SINGLE_DEVICE"):      # rehearsal of the multi-rank path on a one-GPU box
+        local = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        backend = os.environ.get("CSN_DIST_BACKEND", "nccl")     # "nccl" is RCCL on ROCm; gloo only for rehearsals
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend=backend)
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
 
@@ -125,7 +131,8 @@ def main():
             "value": seg_per_s, "unit": "segments/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "cfg2: fused EEG band-pass+z-score -> 2-layer LSTM fwd/bwd -> cosine distill "
+            "config": {"workload": ("cfg2" if (B, C, T, H, L, D) == (256, 128, 500, 768, 2, 384) else "custom") +
+                                   ": fused EEG band-pass+z-score -> LSTM fwd/bwd -> cosine distill "
                                    "-> RMSprop, precomputed random DINOv2-dim targets",
                        "per_gpu_batch": B, "global_batch": B * world, "channels": C, "samples": T, "hidden": H,
                        "layers": L, "embed_dim": D, "parallelism": f"dp{world}"},
@@ -146,6 +153,8 @@ def main():
                 "lstm_fwd_persist_kernel" if pr["fwd_launches"] < T else "lstm_cell_fwd_il_kernel")
             traffic = None      # HBM bytes per launch from the committed PMC passes (profiles/), same workload
             try:
+                if (B, C, T, H, L) != (256, 128, 500, 768, 2):
+                    raise KeyError("PMC passes were collected for cfg2 only")
                 pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
                 traffic = pmc["kernels"][kname]["hbm_bytes_per_launch_corrected"]
             except (OSError, KeyError, ValueError):

@@ -27,3 +27,13 @@ def cuda():
     if not torch.cuda.is_available():
         pytest.fail("GPU test selected (-m gpu) but no GPU is visible")
     return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _native_library():
+    """The HIP library is built in-tree (hipcc cross-compiles without a GPU); build it if it is not there."""
+    from cerebralsignalnetworks_amd import cabi
+    if not os.path.exists(cabi.LIB_PATH):
+        import __graft_entry__ as graft
+        graft.build()
+    yield
