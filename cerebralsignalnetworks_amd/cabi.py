@@ -221,6 +221,7 @@ class LstmPlan:
         off = (-self.workspace.data_ptr()) % 256
         self._ws_ptr = ctypes.c_void_p(self.workspace.data_ptr() + off)
         self.device = device
+        self.busy = False
 
     def key(self):
         d = self.desc

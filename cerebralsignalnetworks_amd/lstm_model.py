@@ -16,16 +16,21 @@ from . import cabi
 
 
 class _LstmFunction(torch.autograd.Function):
-    """Stacked LSTM over libcsn_hip: forward keeps its state in the plan's workspace."""
+    """Stacked LSTM over libcsn_hip.  A training forward keeps its state in a workspace that stays
+    checked out until the matching backward has run, so several forwards (e.g. the multi-crop views of
+    the DINO trainer) can be outstanding at once."""
 
     @staticmethod
-    def forward(ctx, x, plan, want_all, L, *params):
+    def forward(ctx, x, owner, want_all, training, L, *params):
         w_ih, w_hh, b_ih, b_hh = params[0:L], params[L:2 * L], params[2 * L:3 * L], params[3 * L:4 * L]
+        plan = owner._checkout(x.shape[0], x.shape[1], x.device, training)
         y_last, y_all = plan.forward(x, w_ih, w_hh, b_ih, b_hh, want_all=want_all)
-        ctx.plan, ctx.L, ctx.want_all = plan, L, want_all
+        ctx.plan, ctx.owner, ctx.L, ctx.want_all = plan, owner, L, want_all
         ctx.need_dx = x.requires_grad
         ctx.x_shape = x.shape
         ctx.param_like = params
+        if not training:
+            owner._release(plan)
         if want_all:
             return y_last, y_all
         return y_last, y_last.new_empty(0)
@@ -36,8 +41,9 @@ class _LstmFunction(torch.autograd.Function):
         grads = [[torch.empty_like(p) for p in ctx.param_like[g * L:(g + 1) * L]] for g in range(4)]
         dx = torch.empty(ctx.x_shape, dtype=torch.float32, device=dy_last.device) if ctx.need_dx else None
         plan.backward(dy_last, dy_all if ctx.want_all else None, grads, dx=dx)
+        ctx.owner._release(plan)
         flat = [g for group in grads for g in group]
-        return (dx, None, None, None, *flat)
+        return (dx, None, None, None, None, *flat)
 
 
 class HipLSTM(nn.Module):
@@ -47,6 +53,8 @@ class HipLSTM(nn.Module):
     fast path) or torch.float32 (exact-f32 MFMA -- the parity path).
     """
 
+    MAX_IDLE_PLANS = 4      # workspaces are large (8 GB at cfg2): keep only a few idle ones
+
     def __init__(self, input_size, hidden_size, num_layers=1, compute_dtype=torch.bfloat16):
         super().__init__()
         self.input_size, self.hidden_size, self.num_layers = input_size, hidden_size, num_layers
@@ -54,28 +62,40 @@ class HipLSTM(nn.Module):
         ref = nn.LSTM(input_size, hidden_size, num_layers=num_layers, batch_first=True)   # same init + key names
         for name, p in ref.named_parameters():
             self.register_parameter(name, nn.Parameter(p.detach().clone()))
-        self._plans = {}
+        self._plans = {}        # key -> list of plans; plan.busy marks a forward awaiting its backward
 
-    def _plan(self, B, T, device, training):
+    def _checkout(self, B, T, device, training):
         key = (B, T, str(device), bool(training), self.compute_dtype)
-        plan = self._plans.get(key)
-        if plan is None:
-            if len(self._plans) >= 4:          # workspaces are large: keep only the most recent shapes
-                self._plans.pop(next(iter(self._plans)))
-            plan = cabi.LstmPlan(B, T, self.input_size, self.hidden_size, self.num_layers, self.compute_dtype,
-                                 device, training=training)
-            self._plans[key] = plan
+        pool = self._plans.setdefault(key, [])
+        for plan in pool:
+            if not plan.busy:
+                plan.busy = True
+                return plan
+        idle = [(k, pl) for k, lst in self._plans.items() for pl in lst if not pl.busy and k != key]
+        while len(idle) >= self.MAX_IDLE_PLANS:
+            k, pl = idle.pop(0)
+            self._plans[k].remove(pl)
+        plan = cabi.LstmPlan(B, T, self.input_size, self.hidden_size, self.num_layers, self.compute_dtype, device,
+                             training=training)
+        plan.busy = True
+        pool.append(plan)
         return plan
+
+    @staticmethod
+    def _release(plan):
+        plan.busy = False
+
+    def all_plans(self):
+        return [pl for lst in self._plans.values() for pl in lst]
 
     def forward(self, x, want_all=False):
         if not x.is_cuda:
             raise cabi.CsnError("HipLSTM runs on the GPU only (no CPU fallback); move the module and input to cuda")
-        B, T, _ = x.shape
         L = self.num_layers
-        training = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
-        plan = self._plan(B, T, x.device, training)
         params = [getattr(self, f"{n}_l{k}") for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh") for k in range(L)]
-        y_last, y_all = _LstmFunction.apply(x, plan, want_all, L, *params)
+        # (grad mode is off inside Function.forward, so "is a backward coming" is decided here)
+        training = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params))
+        y_last, y_all = _LstmFunction.apply(x, self, want_all, training, L, *params)
         return (y_all, y_last) if want_all else y_last
 
 

@@ -397,7 +397,7 @@ def _run_lstm(p, x, dy_all, dy_last, C, H, L, dtype, cuda, env=None):
         loss = (y_all * dev_t(dy_all, cuda)).sum() + (y_last * dev_t(dy_last, cuda)).sum()
         loss.backward()
         torch.cuda.synchronize()
-        for plan in m.lstm._plans.values():
+        for plan in m.lstm.all_plans():
             assert plan.status() == 0, "an in-kernel hand-off of the weight-stationary forward timed out"
         out = dict(y_all=y_all.detach().cpu().numpy(), dx=xt.grad.cpu().numpy())
         for n, q in m.lstm.named_parameters():
@@ -551,3 +551,29 @@ def test_zero_phase_filtfilt_matches_scipy_golden(cuda, golden):
     # linearity (size-independent property): filtfilt(2.5 x) == 2.5 filtfilt(x)
     y2 = remove_noise(dev_t(2.5 * x, cuda), 1000).cpu().numpy()
     np.testing.assert_allclose(y2, 2.5 * y, atol=1e-5)
+
+
+def test_several_forwards_outstanding_before_backward(cuda):
+    """Multi-crop pattern of LstmDistillation.py:570-585: the same module is run on several views (some of
+    equal length) before one backward; every view keeps its own workspace until its backward has run."""
+    rng = np.random.default_rng(12)
+    B, C, H, L = 6, 16, 32, 2
+    p = lstm.init_params(C, H, L, 8, None, seed=2)
+    lp = {k[len("lstm."):]: v for k, v in p.items() if k.startswith("lstm.")}
+    views = [rng.standard_normal((B, T, C)).astype(np.float32) for T in (30, 30, 20, 20, 20)]
+    w = [rng.standard_normal((B, H)).astype(np.float32) for _ in views]
+    m = _model_from_params(p, C, H, L, 8, None, torch.float32, cuda)
+    total = sum((m.lstm(dev_t(v, cuda)) * dev_t(wi, cuda)).sum() for v, wi in zip(views, w))
+    total.backward()
+    want = {}
+    for v, wi in zip(views, w):
+        y, saved = lstm.lstm_forward(v, lp, L, return_saved=True)
+        dy = np.zeros_like(y)
+        dy[:, -1] = wi
+        _, g = lstm.lstm_backward(dy, lp, saved, L)
+        for k2, gv in g.items():
+            want[k2] = want.get(k2, 0) + gv
+    for k2, gv in want.items():
+        got = getattr(m.lstm, k2).grad.cpu().numpy()
+        np.testing.assert_allclose(got, gv, atol=1e-4 * max(1.0, np.abs(gv).max()), err_msg=k2)
+    assert all(not pl.busy for pl in m.lstm.all_plans())
