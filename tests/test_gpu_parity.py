@@ -577,3 +577,22 @@ def test_several_forwards_outstanding_before_backward(cuda):
         got = getattr(m.lstm, k2).grad.cpu().numpy()
         np.testing.assert_allclose(got, gv, atol=1e-4 * max(1.0, np.abs(gv).max()), err_msg=k2)
     assert all(not pl.busy for pl in m.lstm.all_plans())
+
+
+def test_dino_self_distillation_trainer_runs(cuda, tmp_path):
+    """LstmDistillation.py drop-in: 2 epochs on synthetic 96-channel data, 6 temporal crops per step, EMA teacher,
+    checkpoint dict with the reference's keys."""
+    import LstmDistillation as dino_cli
+    hist = dino_cli.main(["--synthetic", "80", "--batch_size_per_gpu", "16", "--epochs", "2", "--embed_dim", "128",
+                          "--lstm_layers", "2", "--out_dim", "64", "--log_dir", str(tmp_path), "--warmup_epochs", "1",
+                          "--warmup_teacher_temp_epochs", "1"])
+    assert len(hist) == 2 and all(np.isfinite(h) for h in hist)
+    ck = torch.load(os.path.join(str(tmp_path), "checkpoint.pth"), weights_only=False)
+    assert {"student", "teacher", "optimizer", "epoch", "args", "dino_loss"} <= set(ck)
+    assert any(k.startswith("backbone.lstm.weight_hh_l1") for k in ck["teacher"])
+    # the Eval script's loader strips "backbone." (Eval.py:310-313)
+    from LstmDistillFromDinoV2Eval import load_checkpoint_into
+    m = Model(input_size=96, lstm_size=128, lstm_layers=2, output_size=128, include_top=False)
+    torch.save({"teacher": ck["teacher"]}, os.path.join(str(tmp_path), "t.pth"))
+    res = load_checkpoint_into(m, os.path.join(str(tmp_path), "t.pth"))
+    assert not [k for k in res.missing_keys if k.startswith("lstm.")]

@@ -153,3 +153,27 @@ def test_product_lars_and_lr_schedule_match_oracle(golden):
         np.testing.assert_allclose(b.detach().numpy(), g[f"lars_b{it + 1}"], atol=1e-14)
     for s in (0, 7, 50, 73, 99):
         assert barlow_learning_rate(s, 20, 5, 512) == losses.barlow_lr(s, 20, 5, 512)
+
+
+def test_dino_loss_and_schedulers_cpu(golden):
+    """DINO pieces are pure torch (run anywhere): loss value against a numpy restatement of
+    LstmDistillation.py:118-159 incl. its chunk quirk, cosine_scheduler against the reference's own output."""
+    import torch
+    from cerebralsignalnetworks_amd.dino import DINOLoss, cosine_scheduler, temporal_crops
+    g = golden("losses.npz")
+    if "cosine_scheduler" in g.files:
+        np.testing.assert_allclose(cosine_scheduler(0.0005, 1e-6, 10, 7, warmup_epochs=2), g["cosine_scheduler"], atol=0)
+    rng = np.random.default_rng(0)
+    so = rng.standard_normal((6, 5, 32))
+    to = rng.standard_normal((2, 5, 32))
+    crit = DINOLoss(32, 6, 0.04, 0.07, 3, 10)
+    loss = crit(torch.from_numpy(so), torch.from_numpy(to), 1).item()
+    temp = np.linspace(0.04, 0.07, 3)[1]
+    q = losses._softmax(to / temp)                                  # centre is zero at the first step
+    want = np.mean([(-(q * losses._log_softmax(so[v:v + 1] / 0.1)).sum(-1)).mean() for v in range(1, 6)])
+    assert abs(loss - want) < 1e-12
+    assert tuple(crit.center.shape) == (1, 5, 32)                   # the reference's per-sample centre quirk
+    np.testing.assert_allclose(crit.center.numpy(), 0.1 * to.sum(0, keepdims=True) / 2, atol=1e-12)
+    eeg = torch.arange(2 * 495 * 3, dtype=torch.float32).reshape(2, 495, 3)
+    gv, lv = temporal_crops(eeg, rng=np.random.RandomState(1))
+    assert [v.shape[1] for v in gv] == [300, 300] and [v.shape[1] for v in lv] == [200] * 4
