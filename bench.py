@@ -108,10 +108,10 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     loss = None
+    step_losses = []
     for i in range(args.steps):
         loss = step(args.warmup + i)
-        if rank == 0 and not args.no_kernel_timing and i == args.steps - 1:
-            pass
+        step_losses.append(loss)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -121,7 +121,8 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     final_loss = float(loss.item())
-    log(f"timed region done: {elapsed:.3f}s for {args.steps} steps")
+    log(f"timed region done: {elapsed:.3f}s for {args.steps} steps; losses " +
+        " ".join(f"{float(l):.4f}" for l in step_losses))
 
     if rank == 0:
         seg_per_s = world * B * args.steps / elapsed
