@@ -42,7 +42,7 @@ struct LayerWs {
 };
 struct WsLayout {
   LayerWs layer[8];
-  size_t x_c, dy_tm, tn_scratch, colsum, status, total;
+  size_t x_c, dy_tm, tn_scratch, colsum, status, agree, total;
   bool il, persist;
 };
 
@@ -73,7 +73,7 @@ static WsLayout make_layout(const csnLstmDesc& d, int training) {
       L.hblk[1] = take(Bpad * H * 2);
       if (w.persist) {
         L.h_blk_all = take(((size_t)d.T + 1) * Bpad * H * 2);
-        L.counters = take(((size_t)d.T + 1) * (Bpad / 64) * 4);
+        L.counters = take(((size_t)d.T + 1) * (Bpad / 64) * kPersistFlagLine * 4);
       }
     } else {
       L.whh = take(G * H * es);
@@ -98,6 +98,7 @@ static WsLayout make_layout(const csnLstmDesc& d, int training) {
   }
   w.x_c = take(TB * d.I * es);
   w.status = take(256);
+  if (w.persist) w.agree = take(((size_t)d.T + 8) * 8 * sizeof(unsigned long long));   // 8 words per launch
   if (training) {
     w.dy_tm = take(TB * H * 4);
     w.tn_scratch = take(tn_bytes);
@@ -442,11 +443,17 @@ static int forward_il(const csnLstmDesc* d, const WsLayout& w, char* ws, const f
   return CSN_OK;
 }
 
-// Weight-stationary forward (lstm_fwd_persist.hip): layer l runs chunk after chunk on its own stream,
-// the input projection of layer l+1 for a chunk is a GEMM on the side stream as soon as layer l has
-// finished that chunk, and layer l+1's chunk kernel waits for that GEMM.  The two layers' persistent
-// kernels (128 workgroups each at cfg2) occupy all 256 CUs; the GEMM workgroups co-reside with them
-// (registers 408 + 96 per SIMD lane, LDS 100 + 32 KB per CU).
+// Weight-stationary forward (lstm_fwd_persist.hip).
+//
+// Grouped form (the fast one, taken when slots * M-tiles <= 8): ONE launch per chunk diagonal advances layer
+// l through chunk (dg - l) for every layer in range -- at cfg2 two layers x four 64-row M-tiles = 8 hand-off
+// groups of 32 workgroups, one group per XCD under the round-robin dispatch, so a group's h hand-off stays
+// inside one L2 (verified per launch by the kernel; otherwise it uses the placement-independent protocol).
+// The input projection of layer l+1 for the chunk layer l just finished is a GEMM between two launches, on
+// the same stream: the persistent workgroups own every CU (408 VGPRs, 100 KB LDS), nothing co-resides.
+//
+// Stream form (any number of layers / M-tiles): layer l runs chunk after chunk on its own stream, the GEMMs
+// on the side stream, ordered by events; placement-independent hand-off.
 static int forward_persist(const csnLstmDesc* d, const WsLayout& w, char* ws, int training, hipStream_t st,
                            SideCtx* sc, hipStream_t side) {
   const int B = d->B, T = d->T, H = d->H, NL = d->L;
@@ -456,7 +463,63 @@ static int forward_persist(const csnLstmDesc* d, const WsLayout& w, char* ws, in
   const int nch = (T + Cz - 1) / Cz;
   int rc;
   for (int l = 0; l < NL; ++l)
-    CSN_HIP_CHECK(hipMemsetAsync(ws + w.layer[l].counters, 0, ((size_t)T + 1) * MT * 4, st));
+    CSN_HIP_CHECK(hipMemsetAsync(ws + w.layer[l].counters, 0, ((size_t)T + 1) * MT * kPersistFlagLine * 4, st));
+  auto fill_slot = [&](PersistFwdSlot& S, int l, int c) {
+    const LayerWs& L = w.layer[l];
+    S.w_blk = (const bf16_t*)(ws + L.whh_blk);
+    S.xproj = (const float*)(ws + L.xproj);
+    S.gates = training ? (bf16_t*)(ws + L.gates) : nullptr;
+    S.c_all = (float*)(ws + L.c_all);
+    S.h_all = (bf16_t*)(ws + L.h_all);
+    S.h_blk_all = (bf16_t*)(ws + L.h_blk_all);
+    S.flags = (unsigned*)(ws + L.counters);
+    S.t0 = c * Cz;
+    S.nsteps = (S.t0 + Cz <= T) ? Cz : T - S.t0;
+  };
+  auto xproj_gemm = [&](int l, int c, hipStream_t on) {   // layer l finished chunk c -> xproj_{l+1}[chunk c]
+    const LayerWs& L = w.layer[l];
+    const LayerWs& Ln = w.layer[l + 1];
+    const int t0 = c * Cz, nsteps = (t0 + Cz <= T) ? Cz : T - t0;
+    return csn_gemm_nt((const bf16_t*)(ws + L.h_all) + (size_t)(t0 + 1) * B * H, ws + Ln.wih,
+                       (const float*)(ws + Ln.bias), (float*)(ws + Ln.xproj) + (size_t)t0 * B * G,
+                       (int64_t)nsteps * B, G, H, CSN_BF16, CSN_F32, 0, (csnStream_t)on);
+  };
+  PersistFwdArgs a{};
+  a.error_flag = (unsigned*)(ws + w.status);
+  a.B = B; a.H = H; a.T = T; a.Bpad = Bpad; a.MT = MT;
+  int n_launch = 0;
+
+  const int max_slots = NL < nch ? NL : nch;
+  const bool grouped = max_slots <= 4 && max_slots * MT <= 8 && fwd_persist_slices(H) <= 32 &&
+                       getenv("CSN_PERSIST_STREAMS") == nullptr;
+  if (grouped) {
+    const int ndiag = nch + NL - 1;
+    const bool try_local = getenv("CSN_NO_XCD_LOCAL") == nullptr;
+    if (try_local) CSN_HIP_CHECK(hipMemsetAsync(ws + w.agree, 0, (size_t)ndiag * 8 * sizeof(unsigned long long), st));
+    if ((rc = prof_mark(0, st))) return rc;
+    for (int dg = 0; dg < ndiag; ++dg) {
+      int lay[4], ns = 0;
+      for (int l = 0; l < NL; ++l) {
+        const int c = dg - l;
+        if (c < 0 || c >= nch) continue;
+        lay[ns] = l;
+        fill_slot(a.slot[ns++], l, c);
+      }
+      a.nslots = ns;
+      a.xcd_groups = 1;
+      a.agree = try_local ? (unsigned long long*)(ws + w.agree) + (size_t)dg * 8 : nullptr;
+      if ((rc = launch_fwd_persist(a, st))) return rc;
+      ++n_launch;
+      for (int i = 0; i < ns; ++i)
+        if (lay[i] + 1 < NL && (rc = xproj_gemm(lay[i], dg - lay[i], st))) return rc;
+    }
+    if ((rc = prof_mark(1, st))) return rc;
+    g_prof.launches[0] = n_launch;
+    g_prof.cells[0] = T * NL;
+    g_prof.have[0] = g_prof.on;
+    return CSN_OK;
+  }
+
   hipStream_t ls[8];
   ls[0] = st;
   for (int l = 1; l < NL; ++l) {
@@ -464,33 +527,20 @@ static int forward_persist(const csnLstmDesc* d, const WsLayout& w, char* ws, in
     if (ls[l] != st && (rc = hand_off(sc, st, ls[l]))) return rc;
   }
   if (side != st && (rc = hand_off(sc, st, side))) return rc;
-  int n_launch = 0;
   const bool gemm_slot = getenv("CSN_GEMM_SLOT") != nullptr;
   if ((rc = prof_mark(0, st))) return rc;
+  a.nslots = 1;
+  a.xcd_groups = 0;
+  a.agree = nullptr;
   for (int c = 0; c < nch; ++c) {
-    const int t0 = c * Cz, nsteps = (t0 + Cz <= T) ? Cz : T - t0;
     for (int l = 0; l < NL; ++l) {
-      const LayerWs& L = w.layer[l];
-      PersistFwdArgs a{};
-      a.w_blk = (const bf16_t*)(ws + L.whh_blk);
-      a.xproj = (const float*)(ws + L.xproj);
-      a.gates = training ? (bf16_t*)(ws + L.gates) : nullptr;
-      a.c_all = (float*)(ws + L.c_all);
-      a.h_all = (bf16_t*)(ws + L.h_all);
-      a.h_blk_all = (bf16_t*)(ws + L.h_blk_all);
-      a.counters = (unsigned*)(ws + L.counters);
-      a.error_flag = (unsigned*)(ws + w.status);
-      a.B = B; a.H = H; a.T = T; a.t0 = t0; a.nsteps = nsteps; a.Bpad = Bpad;
+      fill_slot(a.slot[0], l, c);
       if ((rc = launch_fwd_persist(a, ls[l]))) return rc;
       ++n_launch;
       if (l + 1 < NL) {
         // layer l finished chunk c -> GEMM xproj_{l+1}[chunk] on the side stream -> layer l+1 may start it
         if ((rc = hand_off(sc, ls[l], side))) return rc;
-        const LayerWs& Ln = w.layer[l + 1];
-        rc = csn_gemm_nt((const bf16_t*)(ws + L.h_all) + (size_t)(t0 + 1) * B * H, ws + Ln.wih,
-                         (const float*)(ws + Ln.bias), (float*)(ws + Ln.xproj) + (size_t)t0 * B * G,
-                         (int64_t)nsteps * B, G, H, CSN_BF16, CSN_F32, 0, (csnStream_t)side);
-        if (rc) return rc;
+        if ((rc = xproj_gemm(l, c, side))) return rc;
         if (side != ls[l + 1] && (rc = hand_off(sc, side, ls[l + 1]))) return rc;
         // optional: the producing layer's next chunk also waits, so the GEMM runs in a slot of its own
         if (gemm_slot && side != ls[l] && (rc = hand_off(sc, side, ls[l]))) return rc;

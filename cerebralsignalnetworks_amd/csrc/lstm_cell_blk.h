@@ -36,19 +36,33 @@ struct CellBwdArgs {
   int B, H;
 };
 
-// weight-stationary forward over a chunk of timesteps of ONE layer (lstm_fwd_persist.hip)
-struct PersistFwdArgs {
+// weight-stationary forward (lstm_fwd_persist.hip): ONE launch advances up to 4 layers, each through its
+// own chunk of timesteps (a wavefront diagonal over chunks).
+struct PersistFwdSlot {
   const bf16_t* w_blk;     // fragment-major W_hh, interleaved rows [4H, H]
   const float* xproj;      // [T, B, 4H] interleaved
   bf16_t* gates;           // [T, B, 4H] interleaved, or null
   float* c_all;            // [T+1, B, H]  (slot t+1 = c_t)
   bf16_t* h_all;           // [T+1, B, H]  row-major
   bf16_t* h_blk_all;       // [T+1][Bpad * H] fragment-major slabs (slot t+1 = h_t); never reused in a forward
-  unsigned* counters;      // [T+1][MT] arrivals per (slot, M-tile), zeroed before the first chunk
+  unsigned* flags;         // [T+1][MT][kPersistFlagLine]: word i of line (t, mt) != 0 once slice i has published h_{t-1}; zeroed per forward
+  int t0, nsteps;
+};
+static constexpr int kPersistFlagLine = 32;    // one 128-byte line per (slot, M-tile): at most 32 slices
+struct PersistFwdArgs {
+  PersistFwdSlot slot[4];
+  int nslots;
+  // xcd_groups != 0: 1-D grid of 8 * nslices workgroups; the workgroups that share (blockIdx.x % 8) form one
+  // hand-off group (a slot's M-tile) -- under the round-robin dispatch they share an XCD, which each group
+  // verifies at run time through agree[group] (zeroed, one set of 8 words per launch) before it uses the
+  // L2-local hand-off.  xcd_groups == 0: groups are contiguous block ranges, placement-independent hand-off.
+  int xcd_groups;
+  unsigned long long* agree;
   unsigned* error_flag;    // sticky: a bounded spin gave up
-  int B, H, T, t0, nsteps, Bpad;
+  int B, H, T, Bpad, MT;
 };
 bool fwd_persist_supported(int B, int H, int dtype);
+int fwd_persist_slices(int H);   // workgroups per hand-off group
 int launch_fwd_persist(const PersistFwdArgs& a, hipStream_t st);
 
 bool cell_blk_supported(int H, int dtype);

@@ -7,22 +7,34 @@
 // registers (each wave: its K quarter of all 4*NQ gate-row tiles = KS*NQ fragments, 144 VGPRs at
 // H = 768) and its cell state c in registers, and per step only streams its 64 rows of h_{t-1}.
 //
-// The step-to-step hand-off of h between the workgroups of one M-tile (the gridDim.x workgroups
-// that share 64 batch rows; different M-tiles never talk) is the placement-independent form of
-// cdna_hip_programming.md Guideline 16 / MI355X_MICROARCH.md "Valid forms", row 1:
-//   producer: h slice stored WRITE-THROUGH (8-byte agent-scope atomic stores = global_store sc1),
-//             every storing wave drains (s_waitcnt vmcnt(0)), workgroup barrier, ONE lane adds 1 to
-//             the arrival counter of (step, M-tile) with an agent-scope atomic;
-//   consumer: ONE lane polls that counter with relaxed agent-scope loads (+ s_sleep), workgroup
-//             barrier, then every load of the handed-off bytes is an sc1 (L1-bypassing) buffer load.
-// On top of that every step's h lives at its OWN address (h_blk_all[t], never reused inside a
-// forward), so no L1 / L2 in the chip can hold an older copy of a line being handed off.
-// Measured per step (tools/persist_bench.hip, 2 layers side by side, H = 768): wait 3.0 us,
-// h loads + MFMA 2.6 us, LDS reduction 0.5 us, epilogue 1.9 us, drain + signal 0.6 us = 8.6 us.
+// One launch advances up to 4 layers, each through its own chunk (a wavefront diagonal over chunks).  A
+// hand-off GROUP is one layer's M-tile (64 batch rows): its nslices workgroups exchange h every step,
+// different groups never talk.  Two hand-off forms, same kernel, bit-identical results:
+//
+//  * L2-local (grouped launch, xcd_groups != 0): group = blockIdx.x % 8.  The hardware deals consecutive
+//    workgroups round-robin over the 8 XCDs, so a group's workgroups share one XCD and one L2 -- at cfg2
+//    2 layers x 4 M-tiles = 8 groups of 32 workgroups = one group per XCD, one workgroup per CU.  That is
+//    an observation, not a contract, so each group VERIFIES it at run time: every workgroup adds
+//    (1, 1 << 6*XCC_ID) to the group's agreement word with an agent-scope atomic and waits for all
+//    arrivals; all then read the same word and take the same decision.  If the group is on one XCD:
+//      producer: h slice with PLAIN stores (they stay in that L2), every storing wave s_waitcnt vmcnt(0),
+//                workgroup barrier, one lane sets the workgroup's word of the group's flag line (plain);
+//      consumer: each wave polls the flags of exactly the producers whose units it multiplies (its K
+//                quarter) with sc1 loads (L1 bypassed, L2-served) and then loads h with sc1 loads.
+//    Measured per step at cfg2 (tools/persist_bench.hip mode 2): wait 0.7 us, h loads + MFMA 1.8,
+//    LDS reduction 0.6, epilogue 2.1, drain + signal 0.5 = 6.2 us (placement-independent form: 8.2 us).
+//  * placement-independent (any grouping; cdna_hip_programming.md Guideline 16 / MI355X_MICROARCH.md
+//    "Valid forms", row 1): the h slice and the flag are written through (agent-scope = sc1 stores), the
+//    polls and every load of the handed-off bytes are sc1 loads.
+//
+// In both forms every step's h lives at its OWN address (h_blk_all[t], never reused inside a forward),
+// so no L1 / L2 in the chip can hold an older copy of a line being handed off, and nothing is queued in
+// a wave's vector-memory pipe ahead of its polls and h loads (results return in issue order: the next
+// step's input projection is requested behind the MFMAs, a full step early -- with it in front of the
+// poll the wait was 2.5 us instead of 0.7).
 // Splitting the 64 rows into two alternating 32-row halves to hide the wait was tried and is slower
-// (12.8 us per step: the half-size loads are latency-bound and the hand-off latency, ~3 us, is as
-// long as a half step), so the whole tile advances together.
-// All gridDim.x * gridDim.y workgroups must be co-resident (1 per CU: 128 at B = 256, H = 768);
+// (12.8 us per step: the half-size loads are latency-bound), so the whole tile advances together.
+// All workgroups of a launch must be co-resident (1 per CU);
 // every spin is bounded: after kSpinTimeoutTicks the workgroup raises *error_flag (sticky: later
 // waits return immediately) so a scheduling accident ends in a reported error, never in a hang.
 #include "csn_common.h"
@@ -35,7 +47,7 @@ __device__ unsigned long long g_pstamps[8];
 #define CSN_PSTAMP(i)                                                          \
   do {                                                                         \
     __builtin_amdgcn_sched_barrier(0);                                         \
-    if (tid == 0 && blockIdx.x == 3 && blockIdx.y == 1) {                      \
+    if (tid == 0 && blockIdx.x == 11) {                                        \
       const unsigned long long now_ = wall_clock64();                          \
       atomicAdd(&g_pstamps[i], now_ - last_);                                  \
       last_ = now_;                                                            \
@@ -66,18 +78,79 @@ __device__ __forceinline__ void store_wt_b64(bf16_t* p, const float (&v)[4]) {
   __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), cvt.u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+__device__ __forceinline__ void store_plain_b64(bf16_t* p, const float (&v)[4]) {
+  *reinterpret_cast<bf16x4*>(p) = (bf16x4){(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+}
+
+// Bounded wait of one lane until *p (read with relaxed agent-scope = sc1 loads, which bypass this CU's L1)
+// satisfies `done`; returns the last value read.  On time-out raises the sticky error flag.
+template <typename T, typename Pred>
+__device__ __forceinline__ T bounded_poll(const T* p, unsigned* error_flag, Pred done) {
+  const unsigned long long t_begin = wall_clock64();
+  T v;
+  while (!done(v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+    __builtin_amdgcn_s_sleep(1);
+    if (__hip_atomic_load(error_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+    if (wall_clock64() - t_begin > kSpinTimeoutTicks) {
+      __hip_atomic_store(error_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      break;
+    }
+  }
+  return v;
+}
+
 template <int NQ, int KS>
 __global__ void __launch_bounds__(256) lstm_fwd_persist_kernel(PersistFwdArgs a) {
   constexpr int NT = 4 * NQ;
   constexpr int NPAIR = 64 * NQ;
   constexpr int NPASS = (NPAIR + 255) / 256;
   extern __shared__ __attribute__((aligned(16))) float4 red[];   // [4][NT][65]
-  const int B = a.B, H = a.H;
+  const int B = a.B, H = a.H, MT = a.MT;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int u0 = blockIdx.x * 4 * NQ, m0 = blockIdx.y * 64, mt = blockIdx.y, MT = gridDim.y;
+  const int nslices = H / (4 * NQ);
+  // hand-off group = (slot, M-tile); a workgroup's place in it = its slice of the hidden units
+  int grp, slice;
+  if (a.xcd_groups) {
+    grp = blockIdx.x & 7;
+    slice = blockIdx.x >> 3;
+    if (grp >= a.nslots * MT) return;
+  } else {
+    grp = blockIdx.x / nslices;
+    slice = blockIdx.x % nslices;
+  }
+  const PersistFwdSlot& S = a.slot[grp / MT];
+  const int mt = grp % MT;
+  const int u0 = slice * 4 * NQ, m0 = mt * 64;
   const int kblocks = H >> 5;
   const int ks_beg = wave * KS;                        // KS = kblocks / 4 k-steps per wave
   const size_t slab = (size_t)a.Bpad * H;              // elements of one fragment-major h slab
+  const bf16_t* const w_blk = S.w_blk;
+  const float* const xproj = S.xproj;
+  bf16_t* const gates = S.gates;
+  float* const c_all = S.c_all;
+  bf16_t* const h_all = S.h_all;
+  bf16_t* const h_blk_all = S.h_blk_all;
+  unsigned* const flags = S.flags + (size_t)mt * kPersistFlagLine;    // [T+1][MT][line]: word i = slice i has published
+  const size_t flag_step = (size_t)MT * kPersistFlagLine;
+  const int t_first = S.t0, nsteps = S.nsteps;
+
+  // ---- is this group on one XCD?  Every workgroup adds (1, 1 << its XCC field) to the group's word and
+  // waits for all `nslices` arrivals; all of them then see the same word and take the same decision.
+  bool local = false;
+  if (a.xcd_groups && a.agree != nullptr) {
+    if (tid == 0) {
+      const unsigned xcc = __builtin_amdgcn_s_getreg(6164) & 7u;        // hwreg(HW_REG_XCC_ID, 0, 4)
+      const unsigned long long mine = 1ull | (1ull << (8 + 6 * xcc));
+      __hip_atomic_fetch_add(a.agree + grp, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned long long v = bounded_poll(a.agree + grp, a.error_flag, [&](unsigned long long x) {
+        return (unsigned)(x & 0xffull) >= (unsigned)nslices;
+      });
+      reinterpret_cast<volatile int*>(red)[0] = (int)(((v >> (8 + 6 * xcc)) & 63ull) == (unsigned long long)nslices);
+    }
+    __syncthreads();
+    local = reinterpret_cast<volatile int*>(red)[0] != 0;
+    __syncthreads();
+  }
 
   // ---- stationary operands: this wave's K quarter of the workgroup's W_hh rows --------------
   bf16x8 wreg[KS][NQ];
@@ -85,7 +158,7 @@ __global__ void __launch_bounds__(256) lstm_fwd_persist_kernel(PersistFwdArgs a)
   for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
     for (int j = 0; j < NQ; ++j)
-      wreg[ks][j] = *reinterpret_cast<const bf16x8*>(a.w_blk + ((int64_t)((u0 >> 2) + j) * kblocks + ks_beg + ks) * 512 + lane * 8);
+      wreg[ks][j] = *reinterpret_cast<const bf16x8*>(w_blk + ((int64_t)((u0 >> 2) + j) * kblocks + ks_beg + ks) * 512 + lane * 8);
 
   // ---- cell state of the (row, unit-quad) pairs this thread owns ------------------------------
   float4 cst[NPASS];
@@ -100,28 +173,38 @@ __global__ void __launch_bounds__(256) lstm_fwd_persist_kernel(PersistFwdArgs a)
     puq[ps] = u0 + 4 * pj[ps];
     pok[ps] = p < NPAIR && prow[ps] < B;
     cst[ps] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (pok[ps] && a.t0 > 0)
-      cst[ps] = *reinterpret_cast<const float4*>(a.c_all + ((size_t)a.t0 * B + prow[ps]) * H + puq[ps]);
+    if (pok[ps] && t_first > 0)
+      cst[ps] = *reinterpret_cast<const float4*>(c_all + ((size_t)t_first * B + prow[ps]) * H + puq[ps]);
   }
 
   const __amdgpu_buffer_rsrc_t hsrc =
-      __builtin_amdgcn_make_buffer_rsrc((void*)a.h_blk_all, 0, (int)((size_t)(a.T + 1) * slab * 2), 0x00020000);
-  const unsigned n_producers = gridDim.x;
+      __builtin_amdgcn_make_buffer_rsrc((void*)h_blk_all, 0, (int)((size_t)(a.T + 1) * slab * 2), 0x00020000);
 #ifdef CSN_PSTAMPS
   unsigned long long last_ = wall_clock64();
 #endif
 
-  for (int s = 0; s < a.nsteps; ++s) {
-    const int t = a.t0 + s;
-    // this step's input projection, requested before the wait so its HBM latency hides under it
-    float4 xp[NPASS][4];
+  float4 xp_next[NPASS][4];
+  auto request_xproj = [&](int t) {
 #pragma unroll
     for (int ps = 0; ps < NPASS; ++ps)
       if (pok[ps]) {
-        const float4* xr = reinterpret_cast<const float4*>(a.xproj + ((size_t)t * B + prow[ps]) * 4 * H + 4 * (size_t)puq[ps]);
+        const float4* xr = reinterpret_cast<const float4*>(xproj + ((size_t)t * B + prow[ps]) * 4 * H + 4 * (size_t)puq[ps]);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) xp[ps][q] = nt_load(xr + q);
+        for (int q = 0; q < 4; ++q) xp_next[ps][q] = nt_load(xr + q);
       }
+  };
+  request_xproj(t_first);
+
+  for (int s = 0; s < nsteps; ++s) {
+    const int t = t_first + s;
+    // this step's input projection was requested a step ago (below, behind the MFMAs): nothing may sit in the
+    // vector-memory queue ahead of the flag polls and the h loads -- results return in issue order, so a queued
+    // HBM read would add its latency to every hand-off (measured: wait 2.5 -> 0.5 us per step)
+    float4 xp[NPASS][4];
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) xp[ps][q] = xp_next[ps][q];
 
     f32x4 acc[4][NQ];
 #pragma unroll
@@ -130,11 +213,15 @@ __global__ void __launch_bounds__(256) lstm_fwd_persist_kernel(PersistFwdArgs a)
       for (int j = 0; j < NQ; ++j) acc[rg][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     if (t > 0) {
-      // wait until every workgroup of this M-tile has published its slice of h_{t-1} (slot t)
-      if (tid == 0) {
-        const unsigned* cnt = a.counters + (size_t)t * MT + mt;
+      // Wait for h_{t-1} (slot t).  A wave only multiplies its K quarter of h, i.e. the units of the
+      // nslices/4 producer slices [wave * nslices/4, ...): it polls exactly those flags of the group's flag
+      // line, lane i the flag of its i-th producer (sc1 loads: L1 bypassed, L2-served), and then loads --
+      // no workgroup barrier, the polling wave is the loading wave.
+      {
+        const int npw = nslices >> 2;
+        const unsigned* fl = flags + (size_t)t * flag_step + wave * npw + (lane < npw ? lane : 0);
         const unsigned long long t_begin = wall_clock64();
-        while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < n_producers) {
+        while (!__all(__hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
           __builtin_amdgcn_s_sleep(1);
           if (__hip_atomic_load(a.error_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
           if (wall_clock64() - t_begin > kSpinTimeoutTicks) {
@@ -143,22 +230,31 @@ __global__ void __launch_bounds__(256) lstm_fwd_persist_kernel(PersistFwdArgs a)
           }
         }
       }
-      __syncthreads();
       CSN_PSTAMP(0);   // wait for h_{t-1}
       const int base = (int)(((size_t)t * slab + ((size_t)(m0 >> 4) * kblocks + ks_beg) * 512 + lane * 8) * 2);
+      // issue order = consumption order (k-step major), pinned, so the MFMAs of k-step ks wait only for its
+      // own 4 loads (counted vmcnt) while the younger ones are still in flight
       bf16x8 hf[KS][4];
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks)
+      for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) hf[ks][rg] = load_sc1_b128(hsrc, base + (rg * kblocks + ks) * 1024);
+        __builtin_amdgcn_sched_barrier(0);
+      }
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks)
+      for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg)
 #pragma unroll
           for (int j = 0; j < NQ; ++j)
             acc[rg][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[ks][j], hf[ks][rg], acc[rg][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
+    // next step's input projection: in flight during this step's reduction and epilogue, landed before the
+    // next poll
+    if (s + 1 < nsteps) request_xproj(t + 1);
+    __builtin_amdgcn_sched_barrier(0);
     CSN_PSTAMP(1);     // h loads + MFMA
 
 #pragma unroll
@@ -192,27 +288,33 @@ __global__ void __launch_bounds__(256) lstm_fwd_persist_kernel(PersistFwdArgs a)
         hn[q] = go[q] * fast_tanh(cn[q]);
       }
       cst[ps] = make_float4(cn[0], cn[1], cn[2], cn[3]);
-      // the hand-off payload first, write-through
-      store_wt_b64(a.h_blk_all + (size_t)(t + 1) * slab + blk_offset(row, uq, H), hn);
-      if (a.gates != nullptr) {
+      // the hand-off payload first: plain stores stay in this XCD's L2 (L2-local groups), write-through otherwise
+      bf16_t* hdst = h_blk_all + (size_t)(t + 1) * slab + blk_offset(row, uq, H);
+      if (local) store_plain_b64(hdst, hn);
+      else store_wt_b64(hdst, hn);
+      if (gates != nullptr) {
         bf16x8 lo = {(bf16_t)gi[0], (bf16_t)gf[0], (bf16_t)gg[0], (bf16_t)go[0], (bf16_t)gi[1], (bf16_t)gf[1], (bf16_t)gg[1], (bf16_t)go[1]};
         bf16x8 hi = {(bf16_t)gi[2], (bf16_t)gf[2], (bf16_t)gg[2], (bf16_t)go[2], (bf16_t)gi[3], (bf16_t)gf[3], (bf16_t)gg[3], (bf16_t)go[3]};
-        bf16x8* gp = reinterpret_cast<bf16x8*>(a.gates + ((size_t)t * B + row) * 4 * H + 4 * (size_t)uq);
+        bf16x8* gp = reinterpret_cast<bf16x8*>(gates + ((size_t)t * B + row) * 4 * H + 4 * (size_t)uq);
         __builtin_nontemporal_store(lo, gp);
         __builtin_nontemporal_store(hi, gp + 1);
       }
       __builtin_nontemporal_store((f32x4){cn[0], cn[1], cn[2], cn[3]},
-                                  reinterpret_cast<f32x4*>(a.c_all + ((size_t)(t + 1) * B + row) * H + uq));
+                                  reinterpret_cast<f32x4*>(c_all + ((size_t)(t + 1) * B + row) * H + uq));
       __builtin_nontemporal_store((bf16x4){(bf16_t)hn[0], (bf16_t)hn[1], (bf16_t)hn[2], (bf16_t)hn[3]},
-                                  reinterpret_cast<bf16x4*>(a.h_all + ((size_t)(t + 1) * B + row) * H + uq));
+                                  reinterpret_cast<bf16x4*>(h_all + ((size_t)(t + 1) * B + row) * H + uq));
     }
     CSN_PSTAMP(3);     // epilogue (LDS reads, math, store issue)
     // publish: every storing wave drains, workgroup barrier (also frees `red`), one lane signals
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     CSN_PSTAMP(4);     // drain + barrier
-    if (tid == 0)
-      __hip_atomic_fetch_add(a.counters + (size_t)(t + 1) * MT + mt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) {
+      unsigned* fl = flags + (size_t)(t + 1) * flag_step + slice;
+      // L2-local groups: a plain store, kept in the one L2 all readers poll; otherwise written through
+      if (local) *fl = 1u;
+      else __hip_atomic_store(fl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     CSN_PSTAMP(5);     // signal
   }
 }
@@ -226,6 +328,8 @@ bool fwd_persist_supported(int B, int H, int dtype) {
   return shape && wgs <= 128;
 }
 
+int fwd_persist_slices(int H) { return H / (4 * ((H % 24 == 0) ? 6 : 8)); }
+
 template <int NQ, int KS>
 static int launch_persist_t(const PersistFwdArgs& a, hipStream_t st) {
   const size_t lds = (size_t)4 * 4 * NQ * 65 * sizeof(float4);
@@ -235,13 +339,20 @@ static int launch_persist_t(const PersistFwdArgs& a, hipStream_t st) {
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_done = true;
   }
-  dim3 grid((unsigned)(a.H / (4 * NQ)), (unsigned)((a.B + 63) / 64));
-  lstm_fwd_persist_kernel<NQ, KS><<<grid, 256, lds, st>>>(a);
+  const unsigned nslices = (unsigned)(a.H / (4 * NQ));
+  const unsigned grid = a.xcd_groups ? 8u * nslices : nslices * (unsigned)(a.MT * a.nslots);
+  lstm_fwd_persist_kernel<NQ, KS><<<dim3(grid), 256, lds, st>>>(a);
   CSN_LAUNCH_CHECK();
   return CSN_OK;
 }
 
 int launch_fwd_persist(const PersistFwdArgs& a, hipStream_t st) {
+  CSN_REQUIRE(a.nslots >= 1 && a.nslots <= 4 && a.MT >= 1, "launch_fwd_persist: bad slot count");
+  CSN_REQUIRE(fwd_persist_slices(a.H) % 4 == 0 && fwd_persist_slices(a.H) <= kPersistFlagLine,
+              "launch_fwd_persist: H=%d gives %d slices (need a multiple of 4, at most %d)", a.H, fwd_persist_slices(a.H),
+              kPersistFlagLine);
+  if (a.xcd_groups)
+    CSN_REQUIRE(a.nslots * a.MT <= 8 && fwd_persist_slices(a.H) <= 32, "launch_fwd_persist: groups do not fit 8 XCDs");
   const int nq = (a.H % 24 == 0) ? 6 : 8, ks = a.H / 128;
   if (nq == 6 && ks == 6) return launch_persist_t<6, 6>(a, st);
   if (nq == 6 && ks == 3) return launch_persist_t<6, 3>(a, st);

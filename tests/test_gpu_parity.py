@@ -438,11 +438,19 @@ def test_fast_path_matches_oracle_and_v1(cuda, B, T, C, H, L, chunk):
                        {"CSN_LSTM_CHUNK": chunk, "CSN_NO_SIDE_STREAM": "1"})
     diag = _run_lstm(p, x, dy_all, dy_last, C, H, L, torch.bfloat16, cuda,
                      {"CSN_LSTM_CHUNK": chunk, "CSN_NO_PERSIST": "1"})
-    # multi-stream schedules compute exactly what the single-stream schedule computes, and the
-    # weight-stationary forward exactly what the per-diagonal launches compute
+    streams = _run_lstm(p, x, dy_all, dy_last, C, H, L, torch.bfloat16, cuda,
+                        {"CSN_LSTM_CHUNK": chunk, "CSN_PERSIST_STREAMS": "1"})
+    anyplace = _run_lstm(p, x, dy_all, dy_last, C, H, L, torch.bfloat16, cuda,
+                         {"CSN_LSTM_CHUNK": chunk, "CSN_NO_XCD_LOCAL": "1"})
+    # multi-stream schedules compute exactly what the single-stream schedule computes, the weight-stationary
+    # forward exactly what the per-diagonal launches compute, and its three hand-off forms (grouped launch with
+    # the L2-local hand-off, grouped launch with the placement-independent one, one launch per layer on its own
+    # stream) exactly the same bits
     for k in fast:
         np.testing.assert_array_equal(fast[k], serial[k], err_msg=k)
         np.testing.assert_array_equal(fast[k], diag[k], err_msg=k)
+        np.testing.assert_array_equal(fast[k], streams[k], err_msg=k)
+        np.testing.assert_array_equal(fast[k], anyplace[k], err_msg=k)
     assert np.abs(fast["y_all"] - y).max() < 3e-2
     assert _rel(fast["dx"], dx_ref) < 4e-2
     for k, v in g_ref.items():
