@@ -141,8 +141,8 @@ def main():
             "model_tflops": seg_per_s * flops_per_seg / 1e12,
         }
         if not args.no_kernel_timing:
-            # dominant kernel = the backward cell launch (one per wavefront diagonal); its average duration
-            # comes from HIP events recorded on the launch stream around the recurrence of the LAST timed step
+            # dominant kernel = the recurrence kernel with the larger total time in the step; its average launch
+            # duration comes from HIP events recorded on the launch stream around its launches of the LAST timed step
             pr = cabi.lstm_profile_read()
             peak = MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else 157.3
             us = {k: (1e3 * pr[k + "_ms"] / max(1, pr[k + "_launches"])) for k in ("fwd", "bwd")}
@@ -150,8 +150,9 @@ def main():
             cells_per_launch = pr[dom + "_cells"] / max(1, pr[dom + "_launches"])
             flops_per_launch = 2.0 * B * 4 * H * H * cells_per_launch     # one recurrent product per cell problem
             ach = flops_per_launch / (us[dom] * 1e-6) / 1e12
-            kname = "lstm_cell_bwd_il_kernel" if dom == "bwd" else (
-                "lstm_fwd_persist_kernel" if pr["fwd_launches"] < T else "lstm_cell_fwd_il_kernel")
+            persist = {k: pr[k + "_launches"] < T for k in ("fwd", "bwd")}     # weight-stationary: one launch per chunk
+            kname = ("lstm_bwd_persist_kernel" if persist["bwd"] else "lstm_cell_bwd_il_kernel") if dom == "bwd" else (
+                "lstm_fwd_persist_kernel" if persist["fwd"] else "lstm_cell_fwd_il_kernel")
             traffic = None      # HBM bytes per launch from the committed PMC passes (profiles/), same workload
             try:
                 if (B, C, T, H, L) != (256, 128, 500, 768, 2):
@@ -164,8 +165,8 @@ def main():
                                "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,
                                "us_per_launch": us, "launches": {k: pr[k + "_launches"] for k in ("fwd", "bwd")},
                                "cells_per_launch": cells_per_launch, "flops_per_launch": flops_per_launch,
-                               "note": "per-timestep recurrent GEMM; limited by operand loads at the per-CU L2 rate "
-                                       "and the launch boundary, not by MFMA issue (DESIGN.md)"}
+                               "note": "recurrent GEMM chain, one hand-off between workgroups per timestep; limited by "
+                                       "the per-step L2 operand stream and hand-off latency, not by MFMA issue (DESIGN.md)"}
         if world == 1 and not args.no_cpu_baseline:
             from oracle import cpu_path, eeg_filter
             log(f"CPU baseline on {cpu_path.usable_cores()} cores")

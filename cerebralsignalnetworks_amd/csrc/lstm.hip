@@ -38,18 +38,19 @@ int launch_cell_bwd(const void* dg_next, const void* w_hh_t, const float* dy, in
 
 struct LayerWs {
   size_t wih, whh, whht, wiht, whh_blk, whht_blk, bias, xproj, gates, c_all, h_all, dgates, dx, dc_carry, hblk[2],
-      dgblk[2], h_blk_all, counters;
+      dgblk[2], h_blk_all, counters, dg_blk_all, bflags;
 };
 struct WsLayout {
   LayerWs layer[8];
   size_t x_c, dy_tm, tn_scratch, colsum, status, agree, total;
-  bool il, persist;
+  bool il, persist, persist_bwd;
 };
 
 static WsLayout make_layout(const csnLstmDesc& d, int training) {
   WsLayout w{};
   w.il = cell_blk_supported(d.H, d.dtype);
   w.persist = w.il && fwd_persist_supported(d.B, d.H, d.dtype) && d.L <= 4;
+  w.persist_bwd = w.persist && training && bwd_persist_supported(d.B, d.H, d.dtype);
   size_t off = 0;
   const size_t es = dtype_size(d.dtype);
   auto take = [&](size_t bytes) {
@@ -90,6 +91,10 @@ static WsLayout make_layout(const csnLstmDesc& d, int training) {
       if (w.il) {
         L.dgblk[0] = take(Bpad * G * 2);
         L.dgblk[1] = take(Bpad * G * 2);
+      }
+      if (w.persist_bwd) {
+        L.dg_blk_all = take((size_t)d.T * Bpad * G * 2);
+        L.bflags = take((size_t)d.T * (Bpad / 64) * kPersistFlagLine * 4);
       }
     }
     size_t a = csn_gemm_tn_scratch_bytes(G, I, TB), b = csn_gemm_tn_scratch_bytes(G, H, TB);
@@ -205,12 +210,30 @@ struct Prof {
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};   // fwd begin/end, bwd begin/end
   int launches[2] = {0, 0}, cells[2] = {0, 0};
   bool have[2] = {false, false};
+  // grouped weight-stationary paths: the recurrence launches alternate with GEMMs on the same stream, so each
+  // launch is bracketed by its own event pair and the reported time is the sum over the pairs
+  std::vector<hipEvent_t> pair[2];
+  size_t pairs_used[2] = {0, 0};
 };
 static Prof g_prof;
 static int prof_mark(int which, hipStream_t st) {
   if (!g_prof.on) return CSN_OK;
+  if ((which & 1) == 0) g_prof.pairs_used[which >> 1] = 0;
   if (g_prof.ev[which] == nullptr) CSN_HIP_CHECK(hipEventCreate(&g_prof.ev[which]));
   CSN_HIP_CHECK(hipEventRecord(g_prof.ev[which], st));
+  return CSN_OK;
+}
+
+static int prof_pair(int k, bool end, hipStream_t st) {   // k: 0 forward, 1 backward
+  if (!g_prof.on) return CSN_OK;
+  const size_t i = 2 * g_prof.pairs_used[k] + (end ? 1 : 0);
+  while (g_prof.pair[k].size() <= i) {
+    hipEvent_t e;
+    CSN_HIP_CHECK(hipEventCreate(&e));
+    g_prof.pair[k].push_back(e);
+  }
+  CSN_HIP_CHECK(hipEventRecord(g_prof.pair[k][i], st));
+  if (end) ++g_prof.pairs_used[k];
   return CSN_OK;
 }
 
@@ -240,7 +263,15 @@ extern "C" int csn_lstm_profile_read(double* fwd_ms, int* fwd_launches, int* fwd
     if (!g_prof.have[k]) continue;
     float ms = 0.f;
     CSN_HIP_CHECK(hipEventSynchronize(g_prof.ev[2 * k + 1]));
-    CSN_HIP_CHECK(hipEventElapsedTime(&ms, g_prof.ev[2 * k], g_prof.ev[2 * k + 1]));
+    if (g_prof.pairs_used[k] > 0) {
+      for (size_t i = 0; i < g_prof.pairs_used[k]; ++i) {
+        float one = 0.f;
+        CSN_HIP_CHECK(hipEventElapsedTime(&one, g_prof.pair[k][2 * i], g_prof.pair[k][2 * i + 1]));
+        ms += one;
+      }
+    } else {
+      CSN_HIP_CHECK(hipEventElapsedTime(&ms, g_prof.ev[2 * k], g_prof.ev[2 * k + 1]));
+    }
     (k == 0 ? *fwd_ms : *bwd_ms) = ms;
     (k == 0 ? *fwd_launches : *bwd_launches) = g_prof.launches[k];
     (k == 0 ? *fwd_cells : *bwd_cells) = g_prof.cells[k];
@@ -487,6 +518,7 @@ static int forward_persist(const csnLstmDesc* d, const WsLayout& w, char* ws, in
   PersistFwdArgs a{};
   a.error_flag = (unsigned*)(ws + w.status);
   a.B = B; a.H = H; a.T = T; a.Bpad = Bpad; a.MT = MT;
+  a.rotate = getenv("CSN_NO_ROTATE") == nullptr;
   int n_launch = 0;
 
   const int max_slots = NL < nch ? NL : nch;
@@ -508,7 +540,9 @@ static int forward_persist(const csnLstmDesc* d, const WsLayout& w, char* ws, in
       a.nslots = ns;
       a.xcd_groups = 1;
       a.agree = try_local ? (unsigned long long*)(ws + w.agree) + (size_t)dg * 8 : nullptr;
+      if ((rc = prof_pair(0, false, st))) return rc;
       if ((rc = launch_fwd_persist(a, st))) return rc;
+      if ((rc = prof_pair(0, true, st))) return rc;
       ++n_launch;
       for (int i = 0; i < ns; ++i)
         if (lay[i] + 1 < NL && (rc = xproj_gemm(lay[i], dg - lay[i], st))) return rc;
@@ -558,10 +592,20 @@ static int forward_persist(const csnLstmDesc* d, const WsLayout& w, char* ws, in
   return CSN_OK;
 }
 
+static int backward_persist(const csnLstmDesc* d, const WsLayout& w, char* ws, const float* dy_last,
+                            const float* dy_tm, float* const* dw_ih, float* const* dw_hh, float* const* db_ih,
+                            float* const* db_hh, float* dx, hipStream_t st);
+
 static int backward_il(const csnLstmDesc* d, const WsLayout& w, char* ws, const float* dy_last, const float* dy_tm,
                        float* const* dw_ih, float* const* dw_hh, float* const* db_ih, float* const* db_hh, float* dx,
                        csnStream_t stream) {
   hipStream_t st = as_stream(stream);
+  if (w.persist_bwd) {
+    const int MTg = (d->B + 63) / 64, nchg = (d->T + chunk_steps() - 1) / chunk_steps();
+    const int slots = d->L < nchg ? d->L : nchg;
+    if (slots <= 4 && slots * MTg <= 8 && getenv("CSN_PERSIST_STREAMS") == nullptr)
+      return backward_persist(d, w, ws, dy_last, dy_tm, dw_ih, dw_hh, db_ih, db_hh, dx, st);
+  }
   SideCtx* sc;
   int rc;
   if ((rc = side_ctx(&sc))) return rc;
@@ -673,6 +717,112 @@ static int backward_il(const csnLstmDesc* d, const WsLayout& w, char* ws, const 
   g_prof.cells[1] = n_cells;
   g_prof.have[1] = g_prof.on;
   return hand_off(sc, side, st);   // the caller's stream resumes after all side-stream work
+}
+
+// Weight-stationary backward recurrence (lstm_bwd_persist.hip), grouped form: ONE launch per chunk diagonal
+// walks layer l backwards through reverse chunk (dg - (L-1-l)); the input gradient of a layer's chunk
+// (dx_l = dgates_l W_ih, the dy of the layer below) is a GEMM between two launches, and the weight / bias
+// gradients follow once the recurrence is complete -- all on the caller's stream: the persistent workgroups
+// own whole CUs, so nothing would overlap them anyway.
+static int backward_persist(const csnLstmDesc* d, const WsLayout& w, char* ws, const float* dy_last,
+                            const float* dy_tm, float* const* dw_ih, float* const* dw_hh, float* const* db_ih,
+                            float* const* db_hh, float* dx, hipStream_t st) {
+  const int B = d->B, T = d->T, H = d->H, NL = d->L;
+  const int64_t G = 4 * (int64_t)H, TB = (int64_t)T * B;
+  const int Bpad = (B + 63) / 64 * 64, MT = Bpad / 64;
+  const int Cz = chunk_steps();
+  const int nch = (T + Cz - 1) / Cz, ndiag = nch + NL - 1;
+  int rc;
+  for (int l = 0; l < NL; ++l) {
+    const LayerWs& L = w.layer[l];
+    CSN_HIP_CHECK(hipMemsetAsync(ws + L.dc_carry, 0, (size_t)B * H * 4, st));
+    CSN_HIP_CHECK(hipMemsetAsync(ws + L.bflags, 0, (size_t)T * MT * kPersistFlagLine * 4, st));
+  }
+  const bool try_local = getenv("CSN_NO_XCD_LOCAL") == nullptr;
+  if (try_local) CSN_HIP_CHECK(hipMemsetAsync(ws + w.agree, 0, (size_t)ndiag * 8 * sizeof(unsigned long long), st));
+
+  PersistBwdArgs a{};
+  a.error_flag = (unsigned*)(ws + w.status);
+  a.B = B; a.H = H; a.T = T; a.Bpad = Bpad; a.MT = MT;
+  a.xcd_groups = 1;
+  a.rotate = getenv("CSN_NO_ROTATE") == nullptr;
+  int n_launch = 0;
+  if ((rc = prof_mark(2, st))) return rc;
+  for (int dg = 0; dg < ndiag; ++dg) {
+    int lay[4], chk[4], ns = 0;
+    for (int l = NL - 1; l >= 0; --l) {
+      const int c = dg - (NL - 1 - l);            // reverse chunk index of layer l on this diagonal
+      if (c < 0 || c >= nch) continue;
+      const LayerWs& L = w.layer[l];
+      PersistBwdSlot& S = a.slot[ns];
+      S.wt_blk = (const bf16_t*)(ws + L.whht_blk);
+      S.gates = (const bf16_t*)(ws + L.gates);
+      S.c_all = (const float*)(ws + L.c_all);
+      if (l == NL - 1) {
+        S.dy = dy_tm;
+        S.dy_last = dy_tm ? nullptr : dy_last;
+      } else {
+        S.dy = (const float*)(ws + w.layer[l + 1].dx);
+        S.dy_last = nullptr;
+      }
+      S.dc_carry = (float*)(ws + L.dc_carry);
+      S.dgates = (bf16_t*)(ws + L.dgates);
+      S.dg_blk_all = (bf16_t*)(ws + L.dg_blk_all);
+      S.flags = (unsigned*)(ws + L.bflags);
+      S.t_hi = T - 1 - c * Cz;
+      S.nsteps = (c * Cz + Cz <= T) ? Cz : T - c * Cz;
+      lay[ns] = l;
+      chk[ns] = c;
+      ++ns;
+    }
+    a.nslots = ns;
+    a.agree = try_local ? (unsigned long long*)(ws + w.agree) + (size_t)dg * 8 : nullptr;
+    if ((rc = prof_pair(1, false, st))) return rc;
+    if ((rc = launch_bwd_persist(a, st))) return rc;
+    if ((rc = prof_pair(1, true, st))) return rc;
+    ++n_launch;
+    for (int i = 0; i < ns; ++i) {
+      const int l = lay[i];
+      if (l == 0) continue;
+      // dx_l[chunk] = dgates_l[chunk] (interleaved K) * W_ih;  Bt = W_ih^T [I, 4H']
+      const LayerWs& L = w.layer[l];
+      const int t_hi = T - 1 - chk[i] * Cz, t_lo = t_hi - a.slot[i].nsteps + 1;
+      rc = csn_gemm_nt((const bf16_t*)(ws + L.dgates) + (size_t)t_lo * B * G, ws + L.wiht, nullptr,
+                       (float*)(ws + L.dx) + (size_t)t_lo * B * H, (int64_t)(t_hi - t_lo + 1) * B, H, G, CSN_BF16,
+                       CSN_F32, 0, (csnStream_t)st);
+      if (rc) return rc;
+    }
+  }
+  if ((rc = prof_mark(3, st))) return rc;
+  g_prof.launches[1] = n_launch;
+  g_prof.cells[1] = T * NL;
+  g_prof.have[1] = g_prof.on;
+
+  if (dx != nullptr) {
+    const LayerWs& L = w.layer[0];
+    if ((rc = csn_gemm_nt(ws + L.dgates, ws + L.wiht, nullptr, ws + L.dx, TB, d->I, G, CSN_BF16, CSN_F32, 0,
+                          (csnStream_t)st)))
+      return rc;
+    tb_to_bt_kernel<<<grid_for(TB * d->I), 256, 0, st>>>((const float*)(ws + L.dx), dx, B, T, d->I);
+    CSN_LAUNCH_CHECK();
+  }
+  for (int l = NL - 1; l >= 0; --l) {
+    const LayerWs& L = w.layer[l];
+    const int64_t I = l == 0 ? d->I : H;
+    const void* inp = l == 0 ? (const void*)(ws + w.x_c)
+                             : (const void*)((const bf16_t*)(ws + w.layer[l - 1].h_all) + (size_t)B * H);
+    float* slabs = (float*)(ws + w.tn_scratch);
+    int S = 1;
+    if ((rc = launch_gemm_tn_slabs(ws + L.dgates, ws + L.h_all, slabs, G, H, TB, CSN_BF16, st, &S))) return rc;
+    if ((rc = launch_reduce_slabs_unperm(slabs, G * H, S, H, H, dw_hh[l], st))) return rc;
+    if ((rc = launch_gemm_tn_slabs(ws + L.dgates, inp, slabs, G, I, TB, CSN_BF16, st, &S))) return rc;
+    if ((rc = launch_reduce_slabs_unperm(slabs, G * I, S, H, I, dw_ih[l], st))) return rc;
+    if ((rc = launch_colsum_partial(ws + L.dgates, TB, G, CSN_BF16, ws + w.colsum, st))) return rc;
+    if ((rc = launch_reduce_slabs_unperm((const float*)(ws + w.colsum), G, colsum_chunks(), H, 1, db_ih[l], st)))
+      return rc;
+    CSN_HIP_CHECK(hipMemcpyAsync(db_hh[l], db_ih[l], (size_t)G * 4, hipMemcpyDeviceToDevice, st));
+  }
+  return CSN_OK;
 }
 
 // =============================================================================================

@@ -1,0 +1,373 @@
+// K3 backward recurrence, weight-stationary form: ONE launch walks up to 4 layers, each backwards through its
+// own chunk of timesteps.  Replaces the per-step body of the autograd backward of nn.LSTM reached from
+// loss.backward() at /root/reference/LstmDistillFromDinoV2Train.py:127 (model at LSTMDistill.py:118,132).
+//
+// Per step and layer:  dh_t = dgates_{t+1} W_hh + dy_t,  then the gate derivatives dgates_t [B, 4H] from dh_t,
+// the carried dc and the saved forward tensors.  In the per-diagonal launches of lstm_cell_blk.hip every
+// workgroup re-reads its W_hh^T slice (295 KB) every step; here a workgroup owns a (64 rows x 16*NUT units)
+// tile for a whole chunk, keeps its W_hh^T slice in registers (each wave: its quarter of K' = 4H for all
+// 16*NUT units = KS*NUT fragments, 192 VGPRs at H = 768) and the carried dc in registers, and per step
+// streams only the 64 rows of dgates_{t+1} (a ring of RING k-blocks in flight per wave).
+//
+// The step-to-step hand-off of dgates between the workgroups of a group (one layer's 64-row M-tile) is the
+// one of lstm_fwd_persist.hip, both forms (L2-local per XCD group, verified at run time; placement-
+// independent write-through otherwise), with per-step slabs dg_blk_all[t] that are never reused inside a
+// backward, per-wave polling of exactly the producers a wave's K quarter covers, and nothing queued in a
+// wave's vector-memory pipe ahead of its polls (the saved tensors of step t-1 are requested behind the
+// MFMAs of step t).  All workgroups of a launch must be co-resident (1 per CU); every spin is bounded and
+// raises the sticky error flag instead of hanging.
+#include "csn_common.h"
+#include "lstm_cell_common.h"
+#include "lstm_cell_blk.h"
+
+#ifdef CSN_PSTAMPS
+__device__ unsigned long long g_bstamps[8];
+#define CSN_BSTAMP(i)                                                          \
+  do {                                                                         \
+    __builtin_amdgcn_sched_barrier(0);                                         \
+    if (tid == 0 && blockIdx.x == 11) {                                        \
+      const unsigned long long now_ = wall_clock64();                          \
+      atomicAdd(&g_bstamps[i], now_ - last_);                                  \
+      last_ = now_;                                                            \
+    }                                                                          \
+    __builtin_amdgcn_sched_barrier(0);                                         \
+  } while (0)
+#else
+#define CSN_BSTAMP(i)
+#endif
+
+namespace csn {
+
+static constexpr unsigned long long kBwdSpinTimeoutTicks = 20000000ull;   // 0.2 s of the 100 MHz wall clock
+
+typedef __attribute__((ext_vector_type(4))) unsigned bu32x4;
+
+__device__ __forceinline__ bf16x8 bload_sc1_b128(__amdgpu_buffer_rsrc_t rsrc, unsigned byte_off) {
+  bu32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)byte_off, 0, 16);   // aux 16 = sc1: L1 bypassed
+  union { bu32x4 u; bf16x8 b; } cvt;
+  cvt.u = v;
+  return cvt.b;
+}
+template <bool WT>
+__device__ __forceinline__ void bstore_b128(__amdgpu_buffer_rsrc_t rsrc, unsigned byte_off, const bf16x8& v) {
+  union { bu32x4 u; bf16x8 b; } cvt;
+  cvt.b = v;
+  __builtin_amdgcn_raw_buffer_store_b128(cvt.u, rsrc, (int)byte_off, 0, WT ? 16 : 0);   // sc1 = write-through
+}
+
+template <int NUT, int KS>
+__global__ void __launch_bounds__(256) lstm_bwd_persist_kernel(PersistBwdArgs a) {
+  constexpr int RING = KS < 6 ? KS : 6;          // k-blocks of dgates in flight per wave
+  constexpr int NT = 4 * NUT;                    // accumulator tiles per wave (4 row groups x NUT unit tiles)
+  constexpr int QPR = 4 * NUT;                   // unit quads per row of the tile
+  constexpr int NPAIR = 64 * QPR;                // (row, unit-quad) pairs
+  constexpr int NPASS = NPAIR / 256;
+  static_assert(NPAIR % 256 == 0, "tile must split evenly over the 256 threads");
+  extern __shared__ __attribute__((aligned(16))) float4 red[];   // [4][NT][65]
+  const int B = a.B, H = a.H, MT = a.MT, T = a.T;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nslices = H / (16 * NUT);
+  int grp, slice;
+  if (a.xcd_groups) {
+    grp = blockIdx.x & 7;
+    slice = blockIdx.x >> 3;
+    if (grp >= a.nslots * MT) return;
+  } else {
+    grp = blockIdx.x / nslices;
+    slice = blockIdx.x % nslices;
+  }
+  const PersistBwdSlot& S = a.slot[grp / MT];
+  const int mt = grp % MT;
+  const int u0 = slice * 16 * NUT, m0 = mt * 64;
+  const int K = 4 * H, kblocks = K >> 5;
+  const int ks_beg = wave * KS;                         // KS = kblocks / 4 k-blocks per wave
+  const size_t slab = (size_t)a.Bpad * K;               // elements of one fragment-major dgates slab
+  const bf16_t* const wt_blk = S.wt_blk;
+  const bf16_t* const gates = S.gates;
+  const float* const c_all = S.c_all;
+  const float* const dy = S.dy;
+  const float* const dy_last = S.dy_last;
+  bf16_t* const dgates = S.dgates;
+  bf16_t* const dg_blk_all = S.dg_blk_all;
+  unsigned* const flags = S.flags + (size_t)mt * kPersistFlagLine;
+  const size_t flag_step = (size_t)MT * kPersistFlagLine;
+  const int t_hi = S.t_hi, nsteps = S.nsteps;
+
+  // ---- is this group on one XCD?  (see lstm_fwd_persist.hip)
+  bool local = false;
+  if (a.xcd_groups && a.agree != nullptr) {
+    if (tid == 0) {
+      const unsigned xcc = __builtin_amdgcn_s_getreg(6164) & 7u;        // hwreg(HW_REG_XCC_ID, 0, 4)
+      const unsigned long long mine = 1ull | (1ull << (8 + 6 * xcc));
+      __hip_atomic_fetch_add(a.agree + grp, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned long long t_begin = wall_clock64();
+      unsigned long long v;
+      while (((v = __hip_atomic_load(a.agree + grp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & 0xffull) <
+             (unsigned long long)nslices) {
+        __builtin_amdgcn_s_sleep(1);
+        if (__hip_atomic_load(a.error_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+        if (wall_clock64() - t_begin > kBwdSpinTimeoutTicks) {
+          __hip_atomic_store(a.error_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
+      }
+      reinterpret_cast<volatile int*>(red)[0] = (int)(((v >> (8 + 6 * xcc)) & 63ull) == (unsigned long long)nslices);
+    }
+    __syncthreads();
+    local = reinterpret_cast<volatile int*>(red)[0] != 0;
+    __syncthreads();
+  }
+
+  // ---- stationary operand: this wave's K' quarter of the workgroup's rows of W_hh^T ----------------
+  // The workgroups of a group all stream the same slab; each starts its walk over the k-blocks at its own
+  // offset (register i holds k-block (i + rot) % KS), so that at any moment they pull different lines and the
+  // requests spread over all L2 channels instead of queueing on the few that hold one 24 KB window.
+  const int rot = a.rotate ? (slice * KS) / nslices : 0;
+  bf16x8 wreg[KS][NUT];
+#pragma unroll
+  for (int kb = 0; kb < KS; ++kb) {
+    const int kk = (kb + rot) % KS;
+#pragma unroll
+    for (int ut = 0; ut < NUT; ++ut)
+      wreg[kb][ut] = *reinterpret_cast<const bf16x8*>(wt_blk + ((int64_t)((u0 >> 4) + ut) * kblocks + ks_beg + kk) * 512 + lane * 8);
+  }
+
+  // ---- the (row, unit-quad) pairs this thread owns: carried dc and the forward's c in registers ----
+  int prow[NPASS], puq[NPASS], prl[NPASS], pjq[NPASS];
+  bool pok[NPASS];
+  float4 dcn[NPASS], cc[NPASS];
+#pragma unroll
+  for (int ps = 0; ps < NPASS; ++ps) {
+    const int p = tid + ps * 256;
+    prl[ps] = p / QPR;
+    pjq[ps] = p % QPR;
+    prow[ps] = m0 + prl[ps];
+    puq[ps] = u0 + 4 * pjq[ps];
+    pok[ps] = prow[ps] < B;
+    dcn[ps] = make_float4(0.f, 0.f, 0.f, 0.f);
+    cc[ps] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (pok[ps]) {
+      dcn[ps] = *reinterpret_cast<const float4*>(S.dc_carry + (size_t)prow[ps] * H + puq[ps]);
+      cc[ps] = *reinterpret_cast<const float4*>(c_all + ((size_t)(t_hi + 1) * B + prow[ps]) * H + puq[ps]);
+    }
+  }
+
+  // saved tensors of one step, requested a full step early (behind the MFMAs of the step before)
+  bf16x8 gt_n[NPASS][2];
+  float4 cpv_n[NPASS], dy_n[NPASS];
+  auto request_saved = [&](int t) {
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+      cpv_n[ps] = make_float4(0.f, 0.f, 0.f, 0.f);
+      dy_n[ps] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (pok[ps]) {
+        const bf16x8* gp = reinterpret_cast<const bf16x8*>(gates + ((size_t)t * B + prow[ps]) * K + 4 * (size_t)puq[ps]);
+        gt_n[ps][0] = nt_load(gp);
+        gt_n[ps][1] = nt_load(gp + 1);
+        cpv_n[ps] = nt_load(reinterpret_cast<const float4*>(c_all + ((size_t)t * B + prow[ps]) * H + puq[ps]));
+        if (dy != nullptr)
+          dy_n[ps] = nt_load(reinterpret_cast<const float4*>(dy + ((size_t)t * B + prow[ps]) * H + puq[ps]));
+        else if (dy_last != nullptr && t == T - 1)
+          dy_n[ps] = *reinterpret_cast<const float4*>(dy_last + (size_t)prow[ps] * H + puq[ps]);
+      }
+    }
+  };
+  request_saved(t_hi);
+#ifdef CSN_PSTAMPS
+  unsigned long long last_ = wall_clock64();
+#endif
+
+  for (int s = 0; s < nsteps; ++s) {
+    const int t = t_hi - s;
+    bf16x8 gt[NPASS][2];
+    float4 cpv[NPASS], dyv[NPASS];
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+      gt[ps][0] = gt_n[ps][0];
+      gt[ps][1] = gt_n[ps][1];
+      cpv[ps] = cpv_n[ps];
+      dyv[ps] = dy_n[ps];
+    }
+
+    f32x4 acc[4][NUT];
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg)
+#pragma unroll
+      for (int ut = 0; ut < NUT; ++ut) acc[rg][ut] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    if (t < T - 1) {
+      // Wait for dgates_{t+1} (slab t+1).  This wave contracts k' in [wave H, (wave+1) H) = the units of the
+      // nslices/4 producer slices [wave nslices/4, ...): it polls exactly those flags (sc1 loads) and then
+      // loads -- the polling wave is the loading wave, no workgroup barrier.
+      {
+        const int npw = nslices >> 2;
+        const unsigned* fl = flags + (size_t)(t + 1) * flag_step + wave * npw + (lane < npw ? lane : 0);
+        const unsigned long long t_begin = wall_clock64();
+        while (!__all(__hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+          __builtin_amdgcn_s_sleep(1);
+          if (__hip_atomic_load(a.error_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+          if (wall_clock64() - t_begin > kBwdSpinTimeoutTicks) {
+            __hip_atomic_store(a.error_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+          }
+        }
+      }
+      CSN_BSTAMP(0);   // wait for dgates_{t+1}
+      const __amdgpu_buffer_rsrc_t src = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)(dg_blk_all + (size_t)(t + 1) * slab), 0, (int)(slab * 2), 0x00020000);
+      const unsigned base = (unsigned)((((size_t)(m0 >> 4) * kblocks + ks_beg) * 512 + lane * 8) * 2);
+      // ring of RING k-blocks: issue order = consumption order (pinned), so the MFMAs of a k-block wait only
+      // for its own 4 loads while the next RING-1 k-blocks are in flight
+      bf16x8 df[RING][4];
+#pragma unroll
+      for (int kb = 0; kb < RING; ++kb) {
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg)
+          df[kb][rg] = bload_sc1_b128(src, base + (unsigned)(rg * kblocks + (kb + rot) % KS) * 1024u);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int kb = 0; kb < KS; ++kb) {
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg)
+#pragma unroll
+          for (int ut = 0; ut < NUT; ++ut)   // D[row = unit][col = batch row]
+            acc[rg][ut] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[kb][ut], df[kb % RING][rg], acc[rg][ut], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (kb + RING < KS) {
+#pragma unroll
+          for (int rg = 0; rg < 4; ++rg)
+            df[kb % RING][rg] = bload_sc1_b128(src, base + (unsigned)(rg * kblocks + (kb + RING + rot) % KS) * 1024u);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+    // the next step's saved tensors: in flight during this step's reduction and epilogue
+    if (s + 1 < nsteps) request_saved(t - 1);
+    __builtin_amdgcn_sched_barrier(0);
+    CSN_BSTAMP(1);     // dgates loads + MFMA
+
+    // lane holds batch row (lane & 15) of row group rg, units 16 ut + (lane >> 4) * 4 + r
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg)
+#pragma unroll
+      for (int ut = 0; ut < NUT; ++ut)
+        red[(wave * NT + rg * NUT + ut) * 65 + lane] = make_float4(acc[rg][ut][0], acc[rg][ut][1], acc[rg][ut][2], acc[rg][ut][3]);
+    __syncthreads();
+    CSN_BSTAMP(2);     // LDS write + barrier
+
+    const __amdgpu_buffer_rsrc_t dst = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(dg_blk_all + (size_t)t * slab), 0, (int)(slab * 2), 0x00020000);
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+      if (!pok[ps]) continue;
+      const int rl = prl[ps], jq = pjq[ps], row = prow[ps], uq = puq[ps];
+      const int idx = ((rl >> 4) * NUT + (jq >> 2)) * 65 + (rl & 15) + 16 * (jq & 3);
+      float4 sm = red[idx];
+#pragma unroll
+      for (int w2 = 1; w2 < 4; ++w2) {
+        const float4 v = red[w2 * NT * 65 + idx];
+        sm.x += v.x; sm.y += v.y; sm.z += v.z; sm.w += v.w;
+      }
+      const float dh[4] = {sm.x + dyv[ps].x, sm.y + dyv[ps].y, sm.z + dyv[ps].z, sm.w + dyv[ps].w};
+      const float cv[4] = {cc[ps].x, cc[ps].y, cc[ps].z, cc[ps].w};
+      const float cpr[4] = {cpv[ps].x, cpv[ps].y, cpv[ps].z, cpv[ps].w};
+      const float dcv[4] = {dcn[ps].x, dcn[ps].y, dcn[ps].z, dcn[ps].w};
+      float out[16], dcarry[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const bf16x8& g8 = gt[ps][q >> 1];
+        const float gi = (float)g8[(q & 1) * 4 + 0], gf = (float)g8[(q & 1) * 4 + 1];
+        const float gg = (float)g8[(q & 1) * 4 + 2], go = (float)g8[(q & 1) * 4 + 3];
+        const float tc = fast_tanh(cv[q]);
+        const float d_o = dh[q] * tc;
+        const float dc = dh[q] * go * (1.0f - tc * tc) + dcv[q];
+        out[4 * q + 0] = dc * gg * gi * (1.0f - gi);
+        out[4 * q + 1] = dc * cpr[q] * gf * (1.0f - gf);
+        out[4 * q + 2] = dc * gi * (1.0f - gg * gg);
+        out[4 * q + 3] = d_o * go * (1.0f - go);
+        dcarry[q] = dc * gf;
+      }
+      bf16x8 lo, hi;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { lo[e] = (bf16_t)out[e]; hi[e] = (bf16_t)out[8 + e]; }
+      // the hand-off payload first: plain stores stay in this XCD's L2 (L2-local groups), write-through otherwise
+      const unsigned o0 = (unsigned)(blk_offset(row, 4 * (int64_t)uq, K) * 2);
+      const unsigned o1 = (unsigned)(blk_offset(row, 4 * (int64_t)uq + 8, K) * 2);
+      if (local) {
+        bstore_b128<false>(dst, o0, lo);
+        bstore_b128<false>(dst, o1, hi);
+      } else {
+        bstore_b128<true>(dst, o0, lo);
+        bstore_b128<true>(dst, o1, hi);
+      }
+      bf16x8* op = reinterpret_cast<bf16x8*>(dgates + ((size_t)t * B + row) * K + 4 * (size_t)uq);
+      nt_store(op, lo);
+      nt_store(op + 1, hi);
+      dcn[ps] = make_float4(dcarry[0], dcarry[1], dcarry[2], dcarry[3]);
+      cc[ps] = cpv[ps];                       // c_{t-1} is the next step's c
+    }
+    CSN_BSTAMP(3);     // epilogue
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    CSN_BSTAMP(4);     // drain + barrier
+    if (tid == 0) {
+      unsigned* fl = flags + (size_t)t * flag_step + slice;
+      if (local) *fl = 1u;
+      else __hip_atomic_store(fl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    CSN_BSTAMP(5);     // signal
+  }
+
+#pragma unroll
+  for (int ps = 0; ps < NPASS; ++ps)
+    if (pok[ps]) *reinterpret_cast<float4*>(S.dc_carry + (size_t)prow[ps] * H + puq[ps]) = dcn[ps];
+}
+
+bool bwd_persist_supported(int B, int H, int dtype) {
+  if (dtype != CSN_BF16 || getenv("CSN_NO_PERSIST") != nullptr || getenv("CSN_NO_PERSIST_BWD") != nullptr) return false;
+  return H == 128 || H == 256 || H == 384 || H == 512 || H == 768;
+}
+int bwd_persist_slices(int H) { return H / 32; }
+
+template <int NUT, int KS>
+static int launch_bwd_persist_t(const PersistBwdArgs& a, hipStream_t st) {
+  const size_t lds = (size_t)4 * 4 * NUT * 65 * sizeof(float4);
+  static bool attr_done = false;
+  if (!attr_done) {
+    CSN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_bwd_persist_kernel<NUT, KS>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_done = true;
+  }
+  const unsigned nslices = (unsigned)(a.H / (16 * NUT));
+  const unsigned grid = a.xcd_groups ? 8u * nslices : nslices * (unsigned)(a.MT * a.nslots);
+  lstm_bwd_persist_kernel<NUT, KS><<<dim3(grid), 256, lds, st>>>(a);
+  CSN_LAUNCH_CHECK();
+  return CSN_OK;
+}
+
+int launch_bwd_persist(const PersistBwdArgs& a, hipStream_t st) {
+  CSN_REQUIRE(a.nslots >= 1 && a.nslots <= 4 && a.MT >= 1, "launch_bwd_persist: bad slot count");
+  const int ns = bwd_persist_slices(a.H);
+  CSN_REQUIRE(ns % 4 == 0 && ns <= kPersistFlagLine, "launch_bwd_persist: H=%d gives %d slices", a.H, ns);
+  if (a.xcd_groups) CSN_REQUIRE(a.nslots * a.MT <= 8, "launch_bwd_persist: groups do not fit 8 XCDs");
+  switch (a.H) {
+    case 768: return launch_bwd_persist_t<2, 24>(a, st);
+    case 512: return launch_bwd_persist_t<2, 16>(a, st);
+    case 384: return launch_bwd_persist_t<2, 12>(a, st);
+    case 256: return launch_bwd_persist_t<2, 8>(a, st);
+    case 128: return launch_bwd_persist_t<2, 4>(a, st);
+  }
+  return fail(CSN_ERR_UNSUPPORTED, "launch_bwd_persist: no kernel for H=%d", a.H);
+}
+
+}  // namespace csn
+
+#ifdef CSN_PSTAMPS
+extern "C" int csn_debug_read_bstamps(unsigned long long* out) {
+  unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bstamps), sizeof(z)) != hipSuccess) return 1;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_bstamps), z, sizeof(z)) != hipSuccess) return 1;
+  return 0;
+}
+#endif

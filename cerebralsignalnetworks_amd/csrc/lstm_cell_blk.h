@@ -57,6 +57,7 @@ struct PersistFwdArgs {
   // verifies at run time through agree[group] (zeroed, one set of 8 words per launch) before it uses the
   // L2-local hand-off.  xcd_groups == 0: groups are contiguous block ranges, placement-independent hand-off.
   int xcd_groups;
+  int rotate;              // != 0: each workgroup walks the k-blocks from its own offset (changes the summation order)
   unsigned long long* agree;
   unsigned* error_flag;    // sticky: a bounded spin gave up
   int B, H, T, Bpad, MT;
@@ -64,6 +65,33 @@ struct PersistFwdArgs {
 bool fwd_persist_supported(int B, int H, int dtype);
 int fwd_persist_slices(int H);   // workgroups per hand-off group
 int launch_fwd_persist(const PersistFwdArgs& a, hipStream_t st);
+
+// weight-stationary backward recurrence (lstm_bwd_persist.hip): ONE launch walks up to 4 layers, each backwards
+// through its own chunk of timesteps; grouping / hand-off as in PersistFwdArgs.
+struct PersistBwdSlot {
+  const bf16_t* wt_blk;    // fragment-major W_hh^T [H, 4H'] (k interleaved)
+  const bf16_t* gates;     // [T, B, 4H] interleaved (saved by the forward)
+  const float* c_all;      // [T+1, B, H]  (slot t+1 = c_t)
+  const float* dy;         // [T, B, H] gradient w.r.t. this layer's output, or null
+  const float* dy_last;    // [B, H] added at t = T-1 when dy is null, or null
+  float* dc_carry;         // [B, H] carried dc, in/out across launches
+  bf16_t* dgates;          // [T, B, 4H] interleaved, row-major (GEMM operand)
+  bf16_t* dg_blk_all;      // [T][Bpad * 4H] fragment-major slabs (slot t = dgates_t); never reused in a backward
+  unsigned* flags;         // [T][MT][kPersistFlagLine], zeroed per backward
+  int t_hi, nsteps;        // steps t_hi, t_hi - 1, ..., t_hi - nsteps + 1
+};
+struct PersistBwdArgs {
+  PersistBwdSlot slot[4];
+  int nslots;
+  int xcd_groups;
+  int rotate;              // != 0: each workgroup walks the k-blocks from its own offset (changes the summation order)
+  unsigned long long* agree;
+  unsigned* error_flag;
+  int B, H, T, Bpad, MT;
+};
+bool bwd_persist_supported(int B, int H, int dtype);
+int bwd_persist_slices(int H);
+int launch_bwd_persist(const PersistBwdArgs& a, hipStream_t st);
 
 bool cell_blk_supported(int H, int dtype);
 int launch_cell_fwd_il(const CellFwdArgs& a, int nprob, hipStream_t st);

@@ -153,12 +153,17 @@ __global__ void __launch_bounds__(256) lstm_fwd_persist_kernel(PersistFwdArgs a)
   }
 
   // ---- stationary operands: this wave's K quarter of the workgroup's W_hh rows --------------
+  // The workgroups of a group all read the same h slab; each walks its k-blocks from its own offset (register i
+  // holds k-block (i + rot) % KS) so that their requests spread over the L2 channels (lstm_bwd_persist.hip).
+  const int rot = a.rotate ? (slice * KS) / nslices : 0;
   bf16x8 wreg[KS][NQ];
 #pragma unroll
-  for (int ks = 0; ks < KS; ++ks)
+  for (int ks = 0; ks < KS; ++ks) {
+    const int kk = (ks + rot) % KS;
 #pragma unroll
     for (int j = 0; j < NQ; ++j)
-      wreg[ks][j] = *reinterpret_cast<const bf16x8*>(w_blk + ((int64_t)((u0 >> 2) + j) * kblocks + ks_beg + ks) * 512 + lane * 8);
+      wreg[ks][j] = *reinterpret_cast<const bf16x8*>(w_blk + ((int64_t)((u0 >> 2) + j) * kblocks + ks_beg + kk) * 512 + lane * 8);
+  }
 
   // ---- cell state of the (row, unit-quad) pairs this thread owns ------------------------------
   float4 cst[NPASS];
@@ -238,7 +243,7 @@ __global__ void __launch_bounds__(256) lstm_fwd_persist_kernel(PersistFwdArgs a)
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
-        for (int rg = 0; rg < 4; ++rg) hf[ks][rg] = load_sc1_b128(hsrc, base + (rg * kblocks + ks) * 1024);
+        for (int rg = 0; rg < 4; ++rg) hf[ks][rg] = load_sc1_b128(hsrc, base + (rg * kblocks + (ks + rot) % KS) * 1024);
         __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll

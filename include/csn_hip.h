@@ -115,9 +115,10 @@ int csn_lstm_backward(const csnLstmDesc* d,
  * a bounded in-kernel wait of the weight-stationary forward gave up (results are invalid). */
 int csn_lstm_read_status(const csnLstmDesc* d, const void* workspace, int training, int* status);
 
-/* Optional timing of the recurrence (the stream of per-timestep cell launches) with HIP events
- * recorded on the caller's stream around the launch loop of the most recent forward / backward.
- * csn_lstm_profile_read synchronises on those events; *_launches = cell launches in the window;
+/* Optional timing of the recurrence kernels with HIP events recorded on the caller's stream in the most
+ * recent forward / backward: around every weight-stationary launch (the time reported is the sum over the
+ * launches, the GEMMs between them excluded), or around the whole launch loop of the per-timestep cell
+ * kernels.  csn_lstm_profile_read synchronises on those events; *_launches = recurrence launches;
  * *_cells = cell problems (layer-steps) those launches advanced. */
 int csn_lstm_profile_enable(int on);
 int csn_lstm_profile_read(double* fwd_ms, int* fwd_launches, int* fwd_cells,

@@ -14,11 +14,14 @@ tr = DistillTrainer(m, EEGFilters(1000, 3).sos, loss="cosine")
 x = torch.randn(B, C, T, device=dev); tg = torch.randn(B, D, device=dev)
 lib = cabi.load()
 lib.csn_debug_read_pstamps.argtypes = [ctypes.POINTER(ctypes.c_ulonglong)]
+lib.csn_debug_read_bstamps.argtypes = [ctypes.POINTER(ctypes.c_ulonglong)]
 buf = (ctypes.c_ulonglong * 8)()
 for it in range(4):
     tr.train_step(x, tg)
     torch.cuda.synchronize()
-    lib.csn_debug_read_pstamps(buf)
-    per = [buf[i] * 0.01 / (T * L) for i in range(6)]
-    print("step %d per-layer-step us: wait %.2f | loads+mfma %.2f | lds %.2f | epilogue %.2f | drain %.2f | signal %.2f | sum %.2f"
-          % (it, *per, sum(per)), flush=True)
+    # the stamping workgroup (blockIdx.x == 11) belongs to ONE layer's group: sums are over that layer's T steps
+    for name, fn in (("fwd", lib.csn_debug_read_pstamps), ("bwd", lib.csn_debug_read_bstamps)):
+        fn(buf)
+        per = [buf[i] * 0.01 / T for i in range(6)]
+        print("step %d %s per-step us: wait %.2f | loads+mfma %.2f | lds %.2f | epilogue %.2f | drain %.2f | signal %.2f | sum %.2f"
+              % (it, name, *per, sum(per)), flush=True)

@@ -41,7 +41,7 @@ int main(int argc, char** argv) {
     S.t0 = 0; S.nsteps = NS;
   }
   a.error_flag = err;
-  a.B = B; a.H = H; a.T = T; a.Bpad = Bpad; a.MT = MT;
+  a.B = B; a.H = H; a.T = T; a.Bpad = Bpad; a.MT = MT; a.rotate = getenv("CSN_NO_ROTATE") == nullptr;
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   for (int rep = 0; rep < 3; ++rep) {
     for (int l = 0; l < NL; ++l) CK(hipMemsetAsync(a.slot[l].flags, 0, (size_t)(T + 1) * MT * kPersistFlagLine * 4, st[0]));
