@@ -373,10 +373,300 @@ gemm_tn_bf16_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ Bm,
   }
 }
 
+// =====================================================================================
+// LDS-DMA variants (global_load_lds, 16 B per lane): no VGPR staging and no ds_write pass -- the tile goes
+// HBM/L2 -> LDS directly, two LDS buffers, ONE barrier per 64-deep k-step, the next tile's loads in flight
+// under the MFMAs of the current one.  An LDS-DMA wave-instruction writes 1 KB lane-linearly (LDS address =
+// wave-uniform base + 16 * lane), so the XOR swizzles of the images above are applied on the SOURCE side:
+// lane i fetches the global chunk whose swizzled position is i (the read side is unchanged).
+// Preconditions (checked by the launchers, otherwise the register-staged kernels run): K % 64 == 0, so no
+// partial k-tile exists (LDS-DMA cannot zero-fill); rows beyond M / N are clamped to the last valid row and
+// their results discarded by the epilogue.
+// =====================================================================================
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+
+__device__ __forceinline__ void glds16(const void* g, void* l) {
+  __builtin_amdgcn_global_load_lds((gbl_ptr_t)g, (lds_ptr_t)l, 16, 0, 0);
+}
+
+template <typename OutT>
+__global__ void __launch_bounds__(256)
+gemm_nt_dma_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ Bt, const float* __restrict__ bias,
+                   OutT* __restrict__ C, int64_t M, int64_t N, int64_t K, int accumulate) {
+  extern __shared__ __attribute__((aligned(1024))) char smem[];  // 2 buffers x (A 16 KB + B 16 KB)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const unsigned ntn = (unsigned)((N + 127) / 128);
+  const unsigned lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int64_t m0 = (int64_t)(lid / ntn) * 128, n0 = (int64_t)(lid % ntn) * 128;
+  const int nk = (int)(K / 64);
+
+  // staging: instruction i of wave w fills rows [(4 i + w) 8, +8) of a tile (8 rows x 8 chunks = 1 KB);
+  // lane -> row r = lane >> 3, LDS chunk position c = lane & 7 <- global chunk c ^ ((row >> 1) & 7)
+  const bf16_t* a_src[4];
+  const bf16_t* b_src[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = (4 * i + wave) * 8 + (lane >> 3);
+    const int ch = (lane & 7) ^ ((row >> 1) & 7);
+    int64_t am = m0 + row, bn = n0 + row;
+    am = am < M ? am : M - 1;
+    bn = bn < N ? bn : N - 1;
+    a_src[i] = A + am * K + ch * 8;
+    b_src[i] = Bt + bn * K + ch * 8;
+  }
+  auto issue = [&](int kt, int buf) {
+    char* a_s = smem + buf * 32768;
+    char* b_s = a_s + 16384;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      glds16(a_src[i] + (int64_t)kt * 64, a_s + (4 * i + wave) * 1024);
+      glds16(b_src[i] + (int64_t)kt * 64, b_s + (4 * i + wave) * 1024);
+    }
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  issue(0, 0);
+  for (int kt = 0; kt < nk; ++kt) {
+    // tile kt has landed (own loads: vmcnt; everyone's: barrier) and every wave is done reading the other buffer
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
+    const char* a_s = smem + (kt & 1) * 32768;
+    const char* b_s = a_s + 16384;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8 af[4], bfr[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        af[i] = *reinterpret_cast<const bf16x8*>(a_s + nt_lds_off(wm * 64 + i * 16 + (lane & 15), kk * 4 + (lane >> 4)));
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        bfr[j] = *reinterpret_cast<const bf16x8*>(b_s + nt_lds_off(wn * 64 + j * 16 + (lane & 15), kk * 4 + (lane >> 4)));
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+    }
+  }
+
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int64_t m = m0 + wm * 64 + i * 16 + (lane & 15);
+    if (m >= M) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t n = n0 + wn * 64 + j * 16 + (lane >> 4) * 4;
+      if (n + 3 < N) {
+        f32x4 v = acc[i][j];
+        if (bias) {
+          const float4 bz = *reinterpret_cast<const float4*>(bias + n);
+          v[0] += bz.x; v[1] += bz.y; v[2] += bz.z; v[3] += bz.w;
+        }
+        if constexpr (sizeof(OutT) == 4) {
+          float4* dst = reinterpret_cast<float4*>((float*)C + m * N + n);
+          if (accumulate) { const float4 o = *dst; v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w; }
+          *dst = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+          bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+          *reinterpret_cast<bf16x4*>((bf16_t*)C + m * N + n) = o;
+        }
+      } else {
+        for (int r = 0; r < 4; ++r)
+          if (n + r < N) {
+            float v = acc[i][j][r] + (bias ? bias[n + r] : 0.f);
+            if constexpr (sizeof(OutT) == 4) {
+              float* dst = (float*)C + m * N + n + r;
+              *dst = accumulate ? *dst + v : v;
+            } else {
+              ((bf16_t*)C)[m * N + n + r] = (bf16_t)v;
+            }
+          }
+      }
+    }
+  }
+}
+
+// TN, 256 x 256 output tile, 8 waves (2 along M x 4 along N, 128 x 64 outputs per wave), LDS-DMA stages of
+// 32 k-rows: per 64 contraction rows a workgroup moves 64 KB for 8.4 MFLOP -- half the L2 bytes per flop of the
+// 128 x 128 tiles, whose ceiling is the aggregate L2 bandwidth (~14 TB/s measured => ~0.9 PFLOP/s).
+// Stage image: 32 k-rows x 256 columns (512-byte rows, 16 blocks of 16 columns), block cb of k-row r at
+// block (cb ^ s(r)) with the s(r) of tn_lds_off, so the 8 k-rows a half-wave of ds_read_b64_tr_b16 touches
+// fall into 8 distinct 32-byte bank windows.
+__device__ __forceinline__ int tn256_lds_off(int krow, int col) {  // byte offset; col in elements
+  const int sw = (krow & 3) | (((krow >> 3) & 1) << 2);
+  return krow * 512 + ((((col >> 4) ^ sw) << 4) + (col & 15)) * 2;
+}
+__device__ __forceinline__ bf16x8 tn256_load_frag(const char* tile, int mbase, int lane) {
+  const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+  union { s16x4 s[2]; bf16x8 b; } u;
+  u.s[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (__attribute__((address_space(3))) s16x4*)(tile + tn256_lds_off(8 * g + q, mbase + 4 * p)));
+  u.s[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (__attribute__((address_space(3))) s16x4*)(tile + tn256_lds_off(8 * g + 4 + q, mbase + 4 * p)));
+  return u.b;
+}
+
+// Pipeline: a ring of NSTAGE stages of 32 k-rows (A 16 KB + B 16 KB each); before the MFMAs of stage h the
+// stages h+1 .. h+NSTAGE-2 are already in flight and stage h+NSTAGE-1 is issued (into the slot of stage h-1,
+// which every wave has left: it passed this step's barrier).  A wave waits for its own part of stage h with a
+// COUNTED vmcnt (4 LDS-DMA instructions per stage and wave) and the raw barrier then covers everybody's part;
+// __syncthreads() would drain the whole ring (it waits vmcnt(0) while LDS-DMA is outstanding).
+// both ds_read_b64_tr_b16 of one 16 x 32 fragment (k-rows q and q + 4 of each 8-row group), LDS byte address
+// relative to the workgroup's LDS base (the dynamic array is the kernel's only LDS object, at offset 0)
+__device__ __forceinline__ bf16x8 tr_read_pair(unsigned addr) {
+  union { s16x4 s[2]; bf16x8 b; } u;
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(u.s[0]) : "v"(addr) : "memory");
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "=v"(u.s[1]) : "v"(addr) : "memory");
+  return u.b;
+}
+
+template <int NSTAGE>
+__global__ void __launch_bounds__(512)
+gemm_tn_256_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ Bm, float* __restrict__ slabs,
+                   int64_t M, int64_t N, int64_t K, int64_t k_per_split) {
+  extern __shared__ __attribute__((aligned(1024))) char smem[];  // NSTAGE x (A 16 KB + B 16 KB)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 2, wn = wave & 3;
+  const unsigned ntn = (unsigned)((N + 255) / 256), ntm = (unsigned)((M + 255) / 256);
+  const unsigned lid = xcd_remap(blockIdx.x, gridDim.x);
+  const unsigned zsplit = lid / (ntm * ntn), rem = lid % (ntm * ntn);
+  const int64_t m0 = (int64_t)(rem / ntn) * 256, n0 = (int64_t)(rem % ntn) * 256;
+  const int64_t kbeg = (int64_t)zsplit * k_per_split;
+  const int64_t kend = (kbeg + k_per_split < K) ? kbeg + k_per_split : K;
+  const int nh = kend > kbeg ? (int)((kend - kbeg) / 32) : 0;     // stages of 32 k-rows
+
+  // staging: instruction i (0..1) of wave w fills k-rows 2 (8 i + w), +1 of a stage (2 rows x 32 chunks = 1 KB);
+  // lane -> k-row r = lane >> 5, LDS chunk position c = lane & 31 <- global columns ((c >> 1) ^ s) * 16 + (c & 1) * 8
+  const bf16_t* a_src[2];
+  const bf16_t* b_src[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int kr = 2 * (8 * i + wave) + (lane >> 5);
+    const int c = lane & 31;
+    const int sw = (kr & 3) | (((kr >> 3) & 1) << 2);
+    const int col = (((c >> 1) ^ sw) << 4) + (c & 1) * 8;
+    int64_t am = m0 + col, bn = n0 + col;
+    am = am + 8 <= M ? am : M - 8;
+    bn = bn + 8 <= N ? bn : N - 8;
+    a_src[i] = A + (kbeg + kr) * M + am;
+    b_src[i] = Bm + (kbeg + kr) * N + bn;
+  }
+  auto issue = [&](int h) {
+    char* a_s = smem + (h % NSTAGE) * 32768;
+    char* b_s = a_s + 16384;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      glds16(a_src[i] + (int64_t)h * 32 * M, a_s + (8 * i + wave) * 1024);
+      glds16(b_src[i] + (int64_t)h * 32 * N, b_s + (8 * i + wave) * 1024);
+    }
+  };
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // byte address (inside a stage) of this lane's first ds_read_b64_tr_b16 of every fragment; the second one
+  // (k-rows + 4) is 2048 bytes further
+  unsigned a_addr[8], b_addr[4];
+  {
+    const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a_addr[i] = (unsigned)tn256_lds_off(8 * g + q, wm * 128 + i * 16 + 4 * pp);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) b_addr[j] = (unsigned)tn256_lds_off(8 * g + q, wn * 64 + j * 16 + 4 * pp);
+  }
+
+#pragma unroll
+  for (int h = 0; h < NSTAGE - 1; ++h)
+    if (h < nh) issue(h);
+  for (int h = 0; h < nh; ++h) {
+    // stages issued after h and still allowed in flight: min(NSTAGE - 2, nh - 1 - h)
+    const int ahead = nh - 1 - h;
+    if (ahead >= NSTAGE - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (NSTAGE - 2)) : "memory");
+    else if (NSTAGE > 3 && ahead == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (h + NSTAGE - 1 < nh) issue(h + NSTAGE - 1);
+    // Fragment reads in inline asm: for an LDS read it can see, the compiler waits vmcnt(0) while ANY LDS-DMA is
+    // outstanding (it cannot tell the stages apart), which would drain the ring every step.  LDS operations
+    // complete in order, so counted lgkmcnt waits release the MFMAs of A tile i while tiles i+1, i+2 are in flight.
+    const unsigned sb = (unsigned)(h % NSTAGE) * 32768u;
+    bf16x8 af[8], bfr[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bfr[j] = tr_read_pair(b_addr[j] + sb + 16384u);
+    af[0] = tr_read_pair(a_addr[0] + sb);
+    af[1] = tr_read_pair(a_addr[1] + sb);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      if (i + 2 < 8) {
+        af[i + 2] = tr_read_pair(a_addr[i + 2] + sb);
+        asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+      } else if (i + 1 < 8) {
+        asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+
+  float* C = slabs + (int64_t)zsplit * M * N;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int64_t m = m0 + wm * 128 + i * 16 + (lane & 15);
+    if (m >= M) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t n = n0 + wn * 64 + j * 16 + (lane >> 4) * 4;
+      if (n + 3 < N && (N & 3) == 0) {
+        *reinterpret_cast<float4*>(C + m * N + n) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+      } else {
+        for (int r = 0; r < 4; ++r)
+          if (n + r < N) C[m * N + n + r] = acc[i][j][r];
+      }
+    }
+  }
+}
+
+template <typename K>
+static int ensure_dyn_lds(K kernel, int bytes) {
+  CSN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  return CSN_OK;
+}
+
 static int tn_splits(int64_t M, int64_t N, int64_t K) {
   const int64_t tiles = ((M + 127) / 128) * ((N + 127) / 128);
   int64_t s = (1024 + tiles - 1) / tiles;          // aim at >= 4 workgroups per CU
   const int64_t max_by_k = (K + 511) / 512;        // keep >= 512 contraction rows per split
+  if (s > max_by_k) s = max_by_k;
+  if (s < 1) s = 1;
+  if (s > 64) s = 64;
+  return (int)s;
+}
+// the 256 x 256 kernel: one workgroup per CU (128 KB of LDS), so the K splits fill the 256 CUs once
+static bool tn_use_256(int64_t M, int64_t N, int64_t K) {
+  return M >= 256 && N >= 256 && K % 64 == 0 && K >= 8192 && getenv("CSN_GEMM_NO_DMA") == nullptr &&
+         getenv("CSN_GEMM_NO_256") == nullptr;
+}
+static int tn_splits_256(int64_t M, int64_t N, int64_t K) {
+  const int64_t tiles = ((M + 255) / 256) * ((N + 255) / 256);
+  int64_t s = 256 / tiles;
+  const int64_t max_by_k = K / 2048;               // keep >= 32 k-steps per split
   if (s > max_by_k) s = max_by_k;
   if (s < 1) s = 1;
   if (s > 64) s = 64;
@@ -403,6 +693,20 @@ extern "C" int csn_gemm_nt(const void* A, const void* Bt, const float* bias, voi
   if (!fast)
     return launch_generic(A, K, 1, Bt, 1, K, bias, C, N, M, N, K, dtype, out_dtype, accumulate, 1, 0, st);
   dim3 grid((unsigned)(((N + 127) / 128) * ((M + 127) / 128)));
+  if (K % 64 == 0 && getenv("CSN_GEMM_NO_DMA") == nullptr) {
+    static bool attr_done = false;
+    if (!attr_done) {
+      if (int rc = ensure_dyn_lds(&gemm_nt_dma_kernel<bf16_t>, 65536)) return rc;
+      if (int rc = ensure_dyn_lds(&gemm_nt_dma_kernel<float>, 65536)) return rc;
+      attr_done = true;
+    }
+    if (out_dtype == CSN_BF16)
+      gemm_nt_dma_kernel<bf16_t><<<grid, 256, 65536, st>>>((const bf16_t*)A, (const bf16_t*)Bt, bias, (bf16_t*)C, M, N, K, 0);
+    else
+      gemm_nt_dma_kernel<float><<<grid, 256, 65536, st>>>((const bf16_t*)A, (const bf16_t*)Bt, bias, (float*)C, M, N, K, accumulate);
+    CSN_LAUNCH_CHECK();
+    return CSN_OK;
+  }
   const bool two = getenv("CSN_GEMM_LDS64") != nullptr;
   if (out_dtype == CSN_BF16) {
     if (two) gemm_nt_bf16_kernel<bf16_t, 2><<<grid, 256, 65536, st>>>((const bf16_t*)A, (const bf16_t*)Bt, bias, (bf16_t*)C, M, N, K, 0);
@@ -417,15 +721,38 @@ extern "C" int csn_gemm_nt(const void* A, const void* Bt, const float* bias, voi
 
 extern "C" size_t csn_gemm_tn_scratch_bytes(int64_t M, int64_t N, int64_t K) {
   if (M <= 0 || N <= 0 || K <= 0) return 0;
-  return (size_t)tn_splits(M, N, K) * (size_t)M * (size_t)N * sizeof(float);
+  const int a = tn_splits(M, N, K), b = tn_use_256(M, N, K) ? tn_splits_256(M, N, K) : 0;
+  return (size_t)(a > b ? a : b) * (size_t)M * (size_t)N * sizeof(float);
 }
 
 namespace csn {
 int launch_gemm_tn_slabs(const void* A, const void* B, float* slabs, int64_t M, int64_t N, int64_t K, int dtype,
                          hipStream_t st, int* S_out) {
+  const bool aligned16 = ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15) == 0;
+  if (dtype == CSN_BF16 && (M % 8 == 0) && (N % 8 == 0) && aligned16 && tn_use_256(M, N, K)) {
+    const int S2 = tn_splits_256(M, N, K);
+    int64_t kper2 = (K + S2 - 1) / S2;
+    kper2 = (kper2 + 63) / 64 * 64;
+    *S_out = S2;
+    static bool attr_done = false;
+    if (!attr_done) {
+      if (int rc = ensure_dyn_lds(&gemm_tn_256_kernel<5>, 5 * 32768)) return rc;
+      if (int rc = ensure_dyn_lds(&gemm_tn_256_kernel<4>, 4 * 32768)) return rc;
+      if (int rc = ensure_dyn_lds(&gemm_tn_256_kernel<3>, 3 * 32768)) return rc;
+      attr_done = true;
+    }
+    dim3 grid((unsigned)(((N + 255) / 256) * ((M + 255) / 256) * S2));
+    const char* ns = getenv("CSN_TN_STAGES");
+    const int nst = ns ? atoi(ns) : 4;
+    if (nst == 3) gemm_tn_256_kernel<3><<<grid, 512, 3 * 32768, st>>>((const bf16_t*)A, (const bf16_t*)B, slabs, M, N, K, kper2);
+    else if (nst == 4) gemm_tn_256_kernel<4><<<grid, 512, 4 * 32768, st>>>((const bf16_t*)A, (const bf16_t*)B, slabs, M, N, K, kper2);
+    else gemm_tn_256_kernel<5><<<grid, 512, 5 * 32768, st>>>((const bf16_t*)A, (const bf16_t*)B, slabs, M, N, K, kper2);
+    CSN_LAUNCH_CHECK();
+    return CSN_OK;
+  }
   const int S = tn_splits(M, N, K);
   int64_t kper = (K + S - 1) / S;
-  kper = (kper + 31) / 32 * 32;
+  kper = (kper + 63) / 64 * 64;
   *S_out = S;
   const bool fast = dtype == CSN_BF16 && (M % 8 == 0) && (N % 8 == 0) &&
                     ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15) == 0 &&

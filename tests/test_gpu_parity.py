@@ -134,6 +134,31 @@ def test_gemm_tn(cuda, M, N, K, dt):
         np.testing.assert_array_equal(c, c_run2)          # split-K combine is order-fixed
 
 
+@pytest.mark.parametrize("M,N,K,stages", [(512, 256, 8192, "5"), (3072, 768, 16000, "5"), (264, 520, 8256, "4"),
+                                            (768, 256, 12800, "3")])
+def test_gemm_tn_256_tile_pipeline(cuda, M, N, K, stages):
+    """The 256 x 256 LDS-DMA weight-gradient kernel (ring of stages, counted waits) against float64 and, bit for
+    bit, against the register-staged 128 x 128 kernel run with the same K split."""
+    rng = np.random.default_rng(M + N + K)
+    a = bf16_round(rng.standard_normal((K, M)).astype(np.float32))
+    b = bf16_round(rng.standard_normal((K, N)).astype(np.float32))
+    want = a.astype(np.float64).T @ b.astype(np.float64)
+    os.environ["CSN_TN_STAGES"] = stages
+    try:
+        c = cabi.gemm_tn(dev_t(a, cuda, torch.bfloat16), dev_t(b, cuda, torch.bfloat16)).cpu().numpy()
+        c2 = cabi.gemm_tn(dev_t(a, cuda, torch.bfloat16), dev_t(b, cuda, torch.bfloat16)).cpu().numpy()
+    finally:
+        del os.environ["CSN_TN_STAGES"]
+    np.testing.assert_allclose(c, want, atol=2e-4 * np.sqrt(K))
+    np.testing.assert_array_equal(c, c2)
+    os.environ["CSN_GEMM_NO_256"] = "1"
+    try:
+        c3 = cabi.gemm_tn(dev_t(a, cuda, torch.bfloat16), dev_t(b, cuda, torch.bfloat16)).cpu().numpy()
+    finally:
+        del os.environ["CSN_GEMM_NO_256"]
+    np.testing.assert_allclose(c, c3, atol=1e-5 * np.sqrt(K))     # different K split: same products, other sum order
+
+
 # ----------------------------------------------------------------------------------------------
 # K3: cell steps, full sequence
 # ----------------------------------------------------------------------------------------------
@@ -437,18 +462,18 @@ def test_fast_path_matches_oracle_and_v1(cuda, B, T, C, H, L, chunk):
     fast = run()
     slow = _run_lstm(p, x, dy_all, dy_last, C, H, L, torch.bfloat16, cuda, {"CSN_CELL_V1": "1"})
     # the schedules / hand-off forms of the default path compute the same bits: single stream instead of side
-    # streams, one launch per layer on its own stream instead of the grouped launch, the placement-independent
-    # hand-off instead of the L2-local one
-    for name, other in (("serial", run(CSN_NO_SIDE_STREAM="1")), ("streams", run(CSN_PERSIST_STREAMS="1")),
-                        ("anyplace", run(CSN_NO_XCD_LOCAL="1"))):
+    # streams, the placement-independent hand-off instead of the L2-local one
+    for name, other in (("serial", run(CSN_NO_SIDE_STREAM="1")), ("anyplace", run(CSN_NO_XCD_LOCAL="1"))):
         for k in fast:
             np.testing.assert_array_equal(fast[k], other[k], err_msg=f"{name}: {k}")
     # with every workgroup walking K in the same order (the default rotates the walk per workgroup, which only
     # reorders the f32 summation), the weight-stationary kernels compute exactly the bits of the per-diagonal
     # launches, forward and backward
     norot = run(CSN_NO_ROTATE="1")
+    # (streams: one forward launch per layer on its own stream instead of the grouped launch, per-diagonal backward)
     for name, other in (("diag", run(CSN_NO_ROTATE="1", CSN_NO_PERSIST="1")),
-                        ("diag_bwd", run(CSN_NO_ROTATE="1", CSN_NO_PERSIST_BWD="1"))):
+                        ("diag_bwd", run(CSN_NO_ROTATE="1", CSN_NO_PERSIST_BWD="1")),
+                        ("streams", run(CSN_NO_ROTATE="1", CSN_PERSIST_STREAMS="1"))):
         for k in norot:
             np.testing.assert_array_equal(norot[k], other[k], err_msg=f"{name}: {k}")
     for k in fast:
