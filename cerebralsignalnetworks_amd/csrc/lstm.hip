@@ -42,7 +42,8 @@ struct LayerWs {
 };
 struct WsLayout {
   LayerWs layer[8];
-  size_t x_c, dy_tm, tn_scratch, colsum, status, agree, total;
+  size_t x_c, x_blk, wih0_blk, dy_tm, tn_scratch, colsum, status, agree, total;
+  bool fuse_x;
   bool il, persist, persist_bwd;
 };
 
@@ -103,6 +104,12 @@ static WsLayout make_layout(const csnLstmDesc& d, int training) {
   }
   w.x_c = take(TB * d.I * es);
   w.status = take(256);
+  // (H = 512 excluded: its 64 x 32-unit tile leaves no registers for the W_ih fragments)
+  w.fuse_x = w.persist && d.I % 32 == 0 && d.I <= 128 && d.H != 512 && getenv("CSN_NO_FUSE_X") == nullptr;
+  if (w.fuse_x) {
+    w.x_blk = take((size_t)d.T * Bpad * d.I * 2);
+    w.wih0_blk = take(G * d.I * 2);
+  }
   if (w.persist) w.agree = take(((size_t)d.T + 8) * 8 * sizeof(unsigned long long));   // 8 words per launch
   if (training) {
     w.dy_tm = take(TB * H * 4);
@@ -413,10 +420,17 @@ static int forward_il(const csnLstmDesc* d, const WsLayout& w, char* ws, const f
     CSN_HIP_CHECK(hipMemsetAsync(ws + L.h_all, 0, (size_t)B * H * 2, st));
     CSN_HIP_CHECK(hipMemsetAsync(ws + L.c_all, 0, (size_t)B * H * 4, st));
   }
-  // layer 0 input projection for every step, main stream
-  if ((rc = csn_gemm_nt(ws + w.x_c, ws + w.layer[0].wih, (const float*)(ws + w.layer[0].bias), ws + w.layer[0].xproj,
-                        TB, G, d->I, CSN_BF16, CSN_F32, 0, stream)))
-    return rc;
+  if (w.fuse_x) {
+    // layer 0 multiplies x_t itself inside the weight-stationary kernel: fragment-major x and W_ih instead of
+    // a [T, B, 4H] float32 projection written to and re-read from HBM
+    if ((rc = launch_blockify_x(x, xsb, xst, B, T, d->I, ws + w.x_blk, st))) return rc;
+    if ((rc = launch_blockify(w_ih[0], d->I, 1, G, d->I, 1, 0, H, ws + w.wih0_blk, st))) return rc;
+  } else {
+    // layer 0 input projection for every step, main stream
+    if ((rc = csn_gemm_nt(ws + w.x_c, ws + w.layer[0].wih, (const float*)(ws + w.layer[0].bias), ws + w.layer[0].xproj,
+                          TB, G, d->I, CSN_BF16, CSN_F32, 0, stream)))
+      return rc;
+  }
   if (w.persist) return forward_persist(d, w, ws, training, st, sc, side);
   if (NL > 1 && (rc = hand_off(sc, st, side))) return rc;   // side stream sees the prepared weights
 
@@ -504,6 +518,16 @@ static int forward_persist(const csnLstmDesc* d, const WsLayout& w, char* ws, in
     S.h_all = (bf16_t*)(ws + L.h_all);
     S.h_blk_all = (bf16_t*)(ws + L.h_blk_all);
     S.flags = (unsigned*)(ws + L.counters);
+    S.x_blk = nullptr;
+    S.wih_blk = nullptr;
+    S.bias = nullptr;
+    S.I = 0;
+    if (l == 0 && w.fuse_x) {
+      S.x_blk = (const bf16_t*)(ws + w.x_blk);
+      S.wih_blk = (const bf16_t*)(ws + w.wih0_blk);
+      S.bias = (const float*)(ws + L.bias);
+      S.I = d->I;
+    }
     S.t0 = c * Cz;
     S.nsteps = (S.t0 + Cz <= T) ? Cz : T - S.t0;
   };

@@ -46,6 +46,12 @@ struct PersistFwdSlot {
   bf16_t* h_all;           // [T+1, B, H]  row-major
   bf16_t* h_blk_all;       // [T+1][Bpad * H] fragment-major slabs (slot t+1 = h_t); never reused in a forward
   unsigned* flags;         // [T+1][MT][kPersistFlagLine]: word i of line (t, mt) != 0 once slice i has published h_{t-1}; zeroed per forward
+  // fused input projection (layer 0, I % 32 == 0, I <= 128): xproj is ignored, the workgroup keeps its W_ih rows
+  // in registers too and multiplies x_t itself
+  const bf16_t* x_blk;     // [T][Bpad * I] fragment-major slabs of the input, or null
+  const bf16_t* wih_blk;   // fragment-major W_ih, interleaved rows [4H, I]
+  const float* bias;       // [4H] interleaved b_ih + b_hh
+  int I;
   int t0, nsteps;
 };
 static constexpr int kPersistFlagLine = 32;    // one 128-byte line per (slot, M-tile): at most 32 slices
@@ -96,6 +102,7 @@ int launch_bwd_persist(const PersistBwdArgs& a, hipStream_t st);
 bool cell_blk_supported(int H, int dtype);
 int launch_cell_fwd_il(const CellFwdArgs& a, int nprob, hipStream_t st);
 int launch_cell_bwd_il(const CellBwdArgs& a, int nprob, hipStream_t st);
+int launch_blockify_x(const float* x, int64_t xsb, int64_t xst, int B, int T, int I, void* dst, hipStream_t st);
 int launch_blockify(const float* src, int64_t ld_r, int64_t ld_k, int64_t R, int64_t K, int perm_r, int perm_k,
                     int64_t H, void* dst, hipStream_t st);
 int launch_permute_rows_cast(const float* src, int64_t H, int64_t I, void* dst, hipStream_t st);

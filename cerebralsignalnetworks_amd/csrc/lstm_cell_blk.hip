@@ -118,6 +118,30 @@ static inline unsigned cap_grid(int64_t n) {
   return (unsigned)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
 }
 
+// x (b, t, i) float32 strided -> [T][Bpad * I] fragment-major bf16 slabs (rows >= B zero)
+__global__ void blockify_x_kernel(const float* __restrict__ x, int64_t xsb, int64_t xst, int B, int Bpad, int T, int I,
+                                  bf16_t* __restrict__ dst) {
+  const int64_t per_t = (int64_t)Bpad * I / 8, nchunks = per_t * T;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int kblocks = I >> 5;
+  for (int64_t ci = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; ci < nchunks; ci += stride) {
+    const int64_t t = ci / per_t, c = ci % per_t;
+    const int64_t blk = c >> 6, lane = c & 63;
+    const int64_t r = (blk / kblocks) * 16 + (lane & 15);
+    const int64_t k = (blk % kblocks) * 32 + 8 * (lane >> 4);
+    bf16x8 v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (bf16_t)(r < B ? x[r * xsb + t * xst + k + j] : 0.f);
+    *reinterpret_cast<bf16x8*>(dst + ci * 8) = v;
+  }
+}
+int launch_blockify_x(const float* x, int64_t xsb, int64_t xst, int B, int T, int I, void* dst, hipStream_t st) {
+  const int Bpad = (B + 63) / 64 * 64;
+  blockify_x_kernel<<<cap_grid((int64_t)T * Bpad * I / 8), 256, 0, st>>>(x, xsb, xst, B, Bpad, T, I, (bf16_t*)dst);
+  CSN_LAUNCH_CHECK();
+  return CSN_OK;
+}
+
 int launch_blockify(const float* src, int64_t ld_r, int64_t ld_k, int64_t R, int64_t K, int perm_r, int perm_k,
                     int64_t H, void* dst, hipStream_t st) {
   blockify_cast_kernel<<<cap_grid(R * K / 8), 256, 0, st>>>(src, ld_r, ld_k, R, K, perm_r, perm_k, H, (bf16_t*)dst);

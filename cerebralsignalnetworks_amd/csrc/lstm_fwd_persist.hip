@@ -104,7 +104,7 @@ __global__ void __launch_bounds__(256) lstm_fwd_persist_kernel(PersistFwdArgs a)
   constexpr int NT = 4 * NQ;
   constexpr int NPAIR = 64 * NQ;
   constexpr int NPASS = (NPAIR + 255) / 256;
-  extern __shared__ __attribute__((aligned(16))) float4 red[];   // [4][NT][65]
+  extern __shared__ __attribute__((aligned(16))) float4 red[];   // [4][NT][65], then [NQ][4] bias
   const int B = a.B, H = a.H, MT = a.MT;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nslices = H / (4 * NQ);
@@ -133,6 +133,11 @@ __global__ void __launch_bounds__(256) lstm_fwd_persist_kernel(PersistFwdArgs a)
   unsigned* const flags = S.flags + (size_t)mt * kPersistFlagLine;    // [T+1][MT][line]: word i = slice i has published
   const size_t flag_step = (size_t)MT * kPersistFlagLine;
   const int t_first = S.t0, nsteps = S.nsteps;
+  // fused input projection: wave w contracts k-block w of the input features (I <= 128: at most one per wave)
+  const bf16_t* const x_blk = S.x_blk;
+  const bool fused = x_blk != nullptr;
+  const int xkb = S.I >> 5;
+  const bool xwave = fused && wave < xkb;
 
   // ---- is this group on one XCD?  Every workgroup adds (1, 1 << its XCC field) to the group's word and
   // waits for all `nslices` arrivals; all of them then see the same word and take the same decision.
@@ -165,6 +170,28 @@ __global__ void __launch_bounds__(256) lstm_fwd_persist_kernel(PersistFwdArgs a)
       wreg[ks][j] = *reinterpret_cast<const bf16x8*>(w_blk + ((int64_t)((u0 >> 2) + j) * kblocks + ks_beg + kk) * 512 + lane * 8);
   }
 
+  // Two register sets of 8 x 16 bytes with a mode-dependent meaning (the modes never mix inside a workgroup):
+  //   plain: cur = this step's input projection xp[pass][quad], nxt = the next step's (in flight)
+  //   fused: cur = this wave's W_ih fragments (stationary), nxt[0..3] = x fragments of the step (in flight a step early)
+  static_assert(NQ <= 8 && NPASS * 4 <= 8, "register sets too small");
+  f32x4 cur[8], nxt[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) cur[i] = nxt[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float* const bias_lds = reinterpret_cast<float*>(red + 4 * NT * 65);      // [NQ][4] float4, behind the reduction buffer
+  if (fused) {
+    if (xwave) {
+#pragma unroll
+      for (int j = 0; j < NQ; ++j)
+        cur[j] = *reinterpret_cast<const f32x4*>(S.wih_blk + ((int64_t)((u0 >> 2) + j) * xkb + wave) * 512 + lane * 8);
+    }
+    // the bias of this workgroup's gate rows in accumulator order: entry (j, lane >> 4) = rows 16 j + 4 (lane >> 4) ..+3
+    if (tid < NQ * 4)
+      reinterpret_cast<float4*>(bias_lds)[tid] =
+          *reinterpret_cast<const float4*>(S.bias + 4 * (size_t)u0 + 16 * (tid >> 2) + 4 * (tid & 3));
+    __syncthreads();
+  }
+  const unsigned xslab = (unsigned)a.Bpad * (unsigned)S.I;    // elements of one x slab
+
   // ---- cell state of the (row, unit-quad) pairs this thread owns ------------------------------
   float4 cst[NPASS];
   int prow[NPASS], puq[NPASS], prl[NPASS], pj[NPASS];
@@ -188,34 +215,52 @@ __global__ void __launch_bounds__(256) lstm_fwd_persist_kernel(PersistFwdArgs a)
   unsigned long long last_ = wall_clock64();
 #endif
 
-  float4 xp_next[NPASS][4];
-  auto request_xproj = [&](int t) {
+  auto request_input = [&](int t) {
+    if (fused) {
+      if (xwave) {
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg)
+          nxt[rg] = nt_load(reinterpret_cast<const f32x4*>(x_blk + (size_t)t * xslab + ((size_t)((m0 >> 4) + rg) * xkb + wave) * 512 + lane * 8));
+      }
+      return;
+    }
 #pragma unroll
     for (int ps = 0; ps < NPASS; ++ps)
       if (pok[ps]) {
-        const float4* xr = reinterpret_cast<const float4*>(xproj + ((size_t)t * B + prow[ps]) * 4 * H + 4 * (size_t)puq[ps]);
+        const f32x4* xr = reinterpret_cast<const f32x4*>(xproj + ((size_t)t * B + prow[ps]) * 4 * H + 4 * (size_t)puq[ps]);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) xp_next[ps][q] = nt_load(xr + q);
+        for (int q = 0; q < 4; ++q) nxt[ps * 4 + q] = nt_load(xr + q);
       }
   };
-  request_xproj(t_first);
+  request_input(t_first);
 
   for (int s = 0; s < nsteps; ++s) {
     const int t = t_first + s;
-    // this step's input projection was requested a step ago (below, behind the MFMAs): nothing may sit in the
-    // vector-memory queue ahead of the flag polls and the h loads -- results return in issue order, so a queued
-    // HBM read would add its latency to every hand-off (measured: wait 2.5 -> 0.5 us per step)
-    float4 xp[NPASS][4];
+    // this step's input projection (or input) was requested a step ago (below, behind the MFMAs): nothing may sit
+    // in the vector-memory queue ahead of the flag polls and the h loads -- results return in issue order, so a
+    // queued HBM read would add its latency to every hand-off (measured: wait 2.5 -> 0.5 us per step)
+    bf16x8 xf[4];
+    if (fused) {
 #pragma unroll
-    for (int ps = 0; ps < NPASS; ++ps)
+      for (int rg = 0; rg < 4; ++rg) xf[rg] = __builtin_bit_cast(bf16x8, nxt[rg]);
+    } else {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) xp[ps][q] = xp_next[ps][q];
+      for (int i = 0; i < 8; ++i) cur[i] = nxt[i];
+    }
 
     f32x4 acc[4][NQ];
 #pragma unroll
     for (int rg = 0; rg < 4; ++rg)
 #pragma unroll
       for (int j = 0; j < NQ; ++j) acc[rg][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (fused && wave == 0) {                 // one wave's partial sum starts from the bias
+#pragma unroll
+      for (int j = 0; j < NQ; ++j) {
+        const float4 bz = reinterpret_cast<const float4*>(bias_lds)[j * 4 + (lane >> 4)];
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) acc[rg][j] = (f32x4){bz.x, bz.y, bz.z, bz.w};
+      }
+    }
 
     if (t > 0) {
       // Wait for h_{t-1} (slot t).  A wave only multiplies its K quarter of h, i.e. the units of the
@@ -239,9 +284,10 @@ __global__ void __launch_bounds__(256) lstm_fwd_persist_kernel(PersistFwdArgs a)
       const int base = (int)(((size_t)t * slab + ((size_t)(m0 >> 4) * kblocks + ks_beg) * 512 + lane * 8) * 2);
       // issue order = consumption order (k-step major), pinned, so the MFMAs of k-step ks wait only for its
       // own 4 loads (counted vmcnt) while the younger ones are still in flight
-      bf16x8 hf[KS][4];
+      constexpr int RING = KS > 4 ? 4 : KS;      // k-blocks of h in flight per wave (registers)
+      bf16x8 hf[RING][4];
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
+      for (int ks = 0; ks < RING; ++ks) {
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) hf[ks][rg] = load_sc1_b128(hsrc, base + (rg * kblocks + (ks + rot) % KS) * 1024);
         __builtin_amdgcn_sched_barrier(0);
@@ -252,13 +298,27 @@ __global__ void __launch_bounds__(256) lstm_fwd_persist_kernel(PersistFwdArgs a)
         for (int rg = 0; rg < 4; ++rg)
 #pragma unroll
           for (int j = 0; j < NQ; ++j)
-            acc[rg][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[ks][j], hf[ks][rg], acc[rg][j], 0, 0, 0);
+            acc[rg][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[ks][j], hf[ks % RING][rg], acc[rg][j], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
+        if (ks + RING < KS) {
+#pragma unroll
+          for (int rg = 0; rg < 4; ++rg)
+            hf[ks % RING][rg] = load_sc1_b128(hsrc, base + (rg * kblocks + (ks + RING + rot) % KS) * 1024);
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
     }
-    // next step's input projection: in flight during this step's reduction and epilogue, landed before the
-    // next poll
-    if (s + 1 < nsteps) request_xproj(t + 1);
+    if (xwave) {                               // x_t W_ih^T, requested a step ago
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg)
+#pragma unroll
+        for (int j = 0; j < NQ; ++j)
+          acc[rg][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, cur[j]), xf[rg], acc[rg][j], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // next step's input projection (or input): in flight during this step's reduction and epilogue, landed
+    // before the next poll
+    if (s + 1 < nsteps) request_input(t + 1);
     __builtin_amdgcn_sched_barrier(0);
     CSN_PSTAMP(1);     // h loads + MFMA
 
@@ -285,10 +345,11 @@ __global__ void __launch_bounds__(256) lstm_fwd_persist_kernel(PersistFwdArgs a)
           const float4 v = red[w2 * NT * 65 + idx];
           sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
         }
-        gi[q] = fast_sigmoid(sum.x + xp[ps][q].x);
-        gf[q] = fast_sigmoid(sum.y + xp[ps][q].y);
-        gg[q] = fast_tanh(sum.z + xp[ps][q].z);
-        go[q] = fast_sigmoid(sum.w + xp[ps][q].w);
+        const f32x4 xq = fused ? (f32x4){0.f, 0.f, 0.f, 0.f} : cur[ps * 4 + q];
+        gi[q] = fast_sigmoid(sum.x + xq[0]);
+        gf[q] = fast_sigmoid(sum.y + xq[1]);
+        gg[q] = fast_tanh(sum.z + xq[2]);
+        go[q] = fast_sigmoid(sum.w + xq[3]);
         cn[q] = gf[q] * cpv[q] + gi[q] * gg[q];
         hn[q] = go[q] * fast_tanh(cn[q]);
       }
@@ -337,7 +398,7 @@ int fwd_persist_slices(int H) { return H / (4 * ((H % 24 == 0) ? 6 : 8)); }
 
 template <int NQ, int KS>
 static int launch_persist_t(const PersistFwdArgs& a, hipStream_t st) {
-  const size_t lds = (size_t)4 * 4 * NQ * 65 * sizeof(float4);
+  const size_t lds = (size_t)(4 * 4 * NQ * 65 + 4 * NQ) * sizeof(float4);
   static bool attr_done = false;
   if (!attr_done) {
     CSN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_fwd_persist_kernel<NQ, KS>),

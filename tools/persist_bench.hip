@@ -38,6 +38,7 @@ int main(int argc, char** argv) {
     S.flags = (unsigned*)dmalloc((size_t)(T + 1) * MT * kPersistFlagLine * 4);
     fill_bf16<<<1024, 256>>>((bf16_t*)S.w_blk, (size_t)G * H, 0.036f, 1 + l);
     fill_f32<<<2048, 256>>>((float*)S.xproj, (size_t)T * B * G, 1.0f, 7 + l);
+    S.x_blk = nullptr; S.wih_blk = nullptr; S.bias = nullptr; S.I = 0;
     S.t0 = 0; S.nsteps = NS;
   }
   a.error_flag = err;
