@@ -480,11 +480,14 @@ def test_fast_path_matches_oracle_and_v1(cuda, B, T, C, H, L, chunk):
     # with every workgroup walking K in the same order (the default rotates the walk per workgroup, which only
     # reorders the f32 summation), the weight-stationary kernels compute exactly the bits of the per-diagonal
     # launches, forward and backward
-    norot = run(CSN_NO_ROTATE="1")
+    # (and with layer 0's input projection as a separate GEMM instead of fused into its kernel, which moves the
+    # x W_ih^T products into the recurrent sum)
+    exact = dict(CSN_NO_ROTATE="1", CSN_NO_FUSE_X="1")
+    norot = run(**exact)
     # (streams: one forward launch per layer on its own stream instead of the grouped launch, per-diagonal backward)
-    for name, other in (("diag", run(CSN_NO_ROTATE="1", CSN_NO_PERSIST="1")),
-                        ("diag_bwd", run(CSN_NO_ROTATE="1", CSN_NO_PERSIST_BWD="1")),
-                        ("streams", run(CSN_NO_ROTATE="1", CSN_PERSIST_STREAMS="1"))):
+    for name, other in (("diag", run(CSN_NO_PERSIST="1", **exact)),
+                        ("diag_bwd", run(CSN_NO_PERSIST_BWD="1", **exact)),
+                        ("streams", run(CSN_PERSIST_STREAMS="1", **exact))):
         for k in norot:
             _assert_same_bits(norot[k], other[k], f"{name}: {k}")
     for k in fast:

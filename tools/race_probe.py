@@ -15,6 +15,18 @@ dy_all = (rng.standard_normal((B, T, H)) * 0.1).astype(np.float32)
 dy_last = rng.standard_normal((B, H)).astype(np.float32)
 run = lambda **env: tg._run_lstm(p, x, dy_all, dy_last, C, H, L, torch.bfloat16, cuda, {"CSN_LSTM_CHUNK": str(chunk), **env})
 exact = dict(CSN_NO_ROTATE="1", CSN_NO_FUSE_X="1")
+if os.environ.get("PROBE_FIRST"):
+    # the very first forward of the process is the default (rotated, fused) one, as in the test
+    fast = run()
+    norot = run(**exact)
+    diag = run(CSN_NO_PERSIST="1", **exact)
+    streams = run(CSN_PERSIST_STREAMS="1", **exact)
+    anyp = run(CSN_NO_XCD_LOCAL="1", **exact)
+    norot2 = run(**exact)
+    for nm, a_, b_ in (("norot/diag", norot, diag), ("streams/diag", streams, diag), ("anyplace/diag", anyp, diag), ("norot2/diag", norot2, diag)):
+        bad = {k: int((a_[k] != b_[k]).sum()) for k in a_ if (a_[k] != b_[k]).any()}
+        print("first", nm, bad, flush=True)
+    sys.exit(0)
 ref = run(CSN_NO_PERSIST="1", **exact)
 for name, env in (("local", {}), ("anyplace", {"CSN_NO_XCD_LOCAL": "1"}), ("streams", {"CSN_PERSIST_STREAMS": "1"}),
                   ("diag again", {"CSN_NO_PERSIST": "1"})):
