@@ -494,6 +494,139 @@ gemm_nt_dma_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ Bt, 
   }
 }
 
+// NT, 256 x 128 output tile, 8 waves (4 along M x 2 along N, 64 x 64 outputs per wave), ring of NSTAGE LDS-DMA
+// stages of 64 contraction columns (A 32 KB + B 16 KB each, the 128-byte-row image and swizzle of nt_lds_off),
+// counted vmcnt + raw barrier, fragment reads in inline asm (see gemm_tn_256_kernel for why).
+__device__ __forceinline__ bf16x8 lds_read_b128(unsigned addr) {
+  bf16x8 v;
+  asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+  return v;
+}
+
+template <typename OutT, int NSTAGE>
+__global__ void __launch_bounds__(512)
+gemm_nt_256_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ Bt, const float* __restrict__ bias,
+                   OutT* __restrict__ C, int64_t M, int64_t N, int64_t K, int accumulate) {
+  extern __shared__ __attribute__((aligned(1024))) char smem[];  // NSTAGE x (A 32 KB + B 16 KB)
+  constexpr unsigned kStage = 49152;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const unsigned ntn = (unsigned)((N + 127) / 128);
+  const unsigned lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int64_t m0 = (int64_t)(lid / ntn) * 256, n0 = (int64_t)(lid % ntn) * 128;
+  const int nk = (int)(K / 64);
+
+  // staging: a 1 KB instruction fills 8 rows x 8 chunks; A has 32 of them per stage (4 per wave), B 16 (2 per
+  // wave); lane -> row r = lane >> 3, LDS chunk position c = lane & 7 <- global chunk c ^ ((row >> 1) & 7)
+  const bf16_t* a_src[4];
+  const bf16_t* b_src[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = (8 * i + wave) * 8 + (lane >> 3);
+    const int ch = (lane & 7) ^ ((row >> 1) & 7);
+    int64_t am = m0 + row;
+    am = am < M ? am : M - 1;
+    a_src[i] = A + am * K + ch * 8;
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = (8 * i + wave) * 8 + (lane >> 3);
+    const int ch = (lane & 7) ^ ((row >> 1) & 7);
+    int64_t bn = n0 + row;
+    bn = bn < N ? bn : N - 1;
+    b_src[i] = Bt + bn * K + ch * 8;
+  }
+  auto issue = [&](int kt) {
+    char* a_s = smem + (kt % NSTAGE) * kStage;
+    char* b_s = a_s + 32768;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) glds16(a_src[i] + (int64_t)kt * 64, a_s + (8 * i + wave) * 1024);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) glds16(b_src[i] + (int64_t)kt * 64, b_s + (8 * i + wave) * 1024);
+  };
+
+  // fragment addresses inside a stage: tile i of A is 2048 bytes further, the second k-half flips chunk bit 2
+  const unsigned sw = (unsigned)((lane & 15) >> 1);
+  const unsigned a_base = (unsigned)((wm * 64 + (lane & 15)) * 128) + ((((unsigned)lane >> 4) ^ sw) << 4);
+  const unsigned b_base = 32768u + (unsigned)((wn * 64 + (lane & 15)) * 128) + ((((unsigned)lane >> 4) ^ sw) << 4);
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+  for (int h = 0; h < NSTAGE - 1; ++h)
+    if (h < nk) issue(h);
+  for (int kt = 0; kt < nk; ++kt) {
+    const int ahead = nk - 1 - kt;            // stages issued after kt: min(NSTAGE - 2, ahead) stay in flight
+    if (ahead >= NSTAGE - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 * (NSTAGE - 2)) : "memory");
+    else if (NSTAGE > 3 && ahead == 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (kt + NSTAGE - 1 < nk) issue(kt + NSTAGE - 1);
+    const unsigned sb = (unsigned)(kt % NSTAGE) * kStage;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const unsigned xo = kk ? 64u : 0u;
+      bf16x8 af[4], bfr[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bfr[j] = lds_read_b128(((b_base ^ xo) + sb) + j * 2048u);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[i] = lds_read_b128(((a_base ^ xo) + sb) + i * 2048u);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (i == 0) asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
+        else if (i == 1) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+        else if (i == 2) asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory");
+        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int64_t m = m0 + wm * 64 + i * 16 + (lane & 15);
+    if (m >= M) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t n = n0 + wn * 64 + j * 16 + (lane >> 4) * 4;
+      if (n + 3 < N) {
+        f32x4 v = acc[i][j];
+        if (bias) {
+          const float4 bz = *reinterpret_cast<const float4*>(bias + n);
+          v[0] += bz.x; v[1] += bz.y; v[2] += bz.z; v[3] += bz.w;
+        }
+        if constexpr (sizeof(OutT) == 4) {
+          float4* dst = reinterpret_cast<float4*>((float*)C + m * N + n);
+          if (accumulate) { const float4 o = *dst; v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w; }
+          *dst = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+          bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+          *reinterpret_cast<bf16x4*>((bf16_t*)C + m * N + n) = o;
+        }
+      } else {
+        for (int r = 0; r < 4; ++r)
+          if (n + r < N) {
+            float v = acc[i][j][r] + (bias ? bias[n + r] : 0.f);
+            if constexpr (sizeof(OutT) == 4) {
+              float* dst = (float*)C + m * N + n + r;
+              *dst = accumulate ? *dst + v : v;
+            } else {
+              ((bf16_t*)C)[m * N + n + r] = (bf16_t)v;
+            }
+          }
+      }
+    }
+  }
+}
+
 // TN, 256 x 256 output tile, 8 waves (2 along M x 4 along N, 128 x 64 outputs per wave), LDS-DMA stages of
 // 32 k-rows: per 64 contraction rows a workgroup moves 64 KB for 8.4 MFLOP -- half the L2 bytes per flop of the
 // 128 x 128 tiles, whose ceiling is the aggregate L2 bandwidth (~14 TB/s measured => ~0.9 PFLOP/s).
@@ -692,6 +825,24 @@ extern "C" int csn_gemm_nt(const void* A, const void* Bt, const float* bias, voi
                     getenv("CSN_GEMM_GENERIC") == nullptr;
   if (!fast)
     return launch_generic(A, K, 1, Bt, 1, K, bias, C, N, M, N, K, dtype, out_dtype, accumulate, 1, 0, st);
+  // 256 x 128 tiles where the tile count still fills the chip a few times over (measured at the LSTM's chunk
+  // shapes: 58 vs 67 us at N = 3072, 56 vs 51 us at N = 768)
+  if (K % 64 == 0 && K >= 256 && M >= 256 && N >= 1024 && getenv("CSN_GEMM_NO_DMA") == nullptr &&
+      getenv("CSN_GEMM_NO_256") == nullptr) {
+    static bool attr_done = false;
+    if (!attr_done) {
+      if (int rc = ensure_dyn_lds(&gemm_nt_256_kernel<bf16_t, 3>, 3 * 49152)) return rc;
+      if (int rc = ensure_dyn_lds(&gemm_nt_256_kernel<float, 3>, 3 * 49152)) return rc;
+      attr_done = true;
+    }
+    dim3 grid256((unsigned)(((N + 127) / 128) * ((M + 255) / 256)));
+    if (out_dtype == CSN_BF16)
+      gemm_nt_256_kernel<bf16_t, 3><<<grid256, 512, 3 * 49152, st>>>((const bf16_t*)A, (const bf16_t*)Bt, bias, (bf16_t*)C, M, N, K, 0);
+    else
+      gemm_nt_256_kernel<float, 3><<<grid256, 512, 3 * 49152, st>>>((const bf16_t*)A, (const bf16_t*)Bt, bias, (float*)C, M, N, K, accumulate);
+    CSN_LAUNCH_CHECK();
+    return CSN_OK;
+  }
   dim3 grid((unsigned)(((N + 127) / 128) * ((M + 127) / 128)));
   if (K % 64 == 0 && getenv("CSN_GEMM_NO_DMA") == nullptr) {
     static bool attr_done = false;

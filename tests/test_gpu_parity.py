@@ -92,7 +92,9 @@ def test_mfma_layout_identity_times_asymmetric(cuda):
         np.testing.assert_allclose(c2, bf16_round(b) if dt == torch.bfloat16 else b, atol=1e-6)
 
 
-@pytest.mark.parametrize("M,N,K", [(256, 384, 128), (300, 260, 72), (128, 128, 64), (64, 3072, 768), (70, 52, 40)])
+@pytest.mark.parametrize("M,N,K", [(256, 384, 128), (300, 260, 72), (128, 128, 64), (64, 3072, 768), (70, 52, 40),
+                                   (1024, 3072, 768), (520, 1028, 320),     # 256 x 128 LDS-DMA ring kernel
+                                   (512, 768, 3072)])                       # 128 x 128 LDS-DMA kernel
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
 def test_gemm_nt(cuda, M, N, K, dt):
     rng = np.random.default_rng(M + N + K)
