@@ -147,26 +147,44 @@ def main():
             peak = MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else 157.3
             us = {k: (1e3 * pr[k + "_ms"] / max(1, pr[k + "_launches"])) for k in ("fwd", "bwd")}
             dom = "bwd" if pr["bwd_ms"] >= pr["fwd_ms"] else "fwd"      # largest total time in the step
-            cells_per_launch = pr[dom + "_cells"] / max(1, pr[dom + "_launches"])
-            flops_per_launch = 2.0 * B * 4 * H * H * cells_per_launch     # one recurrent product per cell problem
-            ach = flops_per_launch / (us[dom] * 1e-6) / 1e12
             persist = {k: pr[k + "_launches"] < T for k in ("fwd", "bwd")}     # weight-stationary: one launch per chunk
             kname = ("lstm_bwd_persist_kernel" if persist["bwd"] else "lstm_cell_bwd_il_kernel") if dom == "bwd" else (
                 "lstm_fwd_persist_kernel" if persist["fwd"] else "lstm_cell_fwd_il_kernel")
+            cells_per_launch = pr[dom + "_cells"] / max(1, pr[dom + "_launches"])
+            # algorithmic work of one cell problem (one layer, one timestep):
+            #   flops: the recurrent product 2 * B * 4H * H
+            #   HBM bytes, backward: read gates (bf16 4H) + c_{t-1} (f32 H) + dy (f32 H), write dgates (bf16 4H)
+            #   HBM bytes, forward : read the input projection (f32 4H), write gates (bf16 4H) + c (f32 H) + h (bf16 H)
+            flops_per_launch = 2.0 * B * 4 * H * H * cells_per_launch
+            bytes_per_cell = B * H * (24.0 if dom == "bwd" else 30.0)
+            bytes_per_launch = bytes_per_cell * cells_per_launch
+            t_launch = us[dom] * 1e-6
+            ach_tf = flops_per_launch / t_launch / 1e12
+            ach_gb = bytes_per_launch / t_launch / 1e9
+            # the binding roofline is the one with the larger minimum time
+            hbm_bound = bytes_per_launch / (HBM_PEAK_GBS * 1e9) >= flops_per_launch / (peak * 1e12)
             traffic = None      # HBM bytes per launch from the committed PMC passes (profiles/), same workload
             try:
                 if (B, C, T, H, L) != (256, 128, 500, 768, 2):
                     raise KeyError("PMC passes were collected for cfg2 only")
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_d_pmc_traffic.json")))
                 traffic = pmc["kernels"][kname]["hbm_bytes_per_launch_corrected"]
             except (OSError, KeyError, ValueError):
                 pass
-            res["roofline"] = {"bound": "mfma", "kernel": kname, "achieved": ach, "peak": peak,
-                               "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,
+            res["roofline"] = {"bound": "hbm" if hbm_bound else "mfma", "kernel": kname,
+                               "achieved": ach_gb if hbm_bound else ach_tf,
+                               "peak": HBM_PEAK_GBS if hbm_bound else peak,
+                               "unit": "GB/s" if hbm_bound else "TFLOP/s",
+                               "frac": (ach_gb / HBM_PEAK_GBS) if hbm_bound else (ach_tf / peak), "traffic": traffic,
+                               "algorithmic_bytes_per_launch": bytes_per_launch, "flops_per_launch": flops_per_launch,
+                               "other_roofline": {"bound": "mfma" if hbm_bound else "hbm",
+                                                  "achieved": ach_tf if hbm_bound else ach_gb,
+                                                  "frac": (ach_tf / peak) if hbm_bound else (ach_gb / HBM_PEAK_GBS)},
                                "us_per_launch": us, "launches": {k: pr[k + "_launches"] for k in ("fwd", "bwd")},
-                               "cells_per_launch": cells_per_launch, "flops_per_launch": flops_per_launch,
-                               "note": "recurrent GEMM chain, one hand-off between workgroups per timestep; limited by "
-                                       "the per-step L2 operand stream and hand-off latency, not by MFMA issue (DESIGN.md)"}
+                               "cells_per_launch": cells_per_launch,
+                               "note": "recurrent GEMM chain with one hand-off between workgroups per timestep; neither "
+                                       "roofline binds: the step is paced by the per-step operand stream from L2 and "
+                                       "the hand-off latency (DESIGN.md section 3)"}
         if world == 1 and not args.no_cpu_baseline:
             from oracle import cpu_path, eeg_filter
             log(f"CPU baseline on {cpu_path.usable_cores()} cores")
