@@ -74,6 +74,8 @@ int launch_colsum(const void* X, int64_t R, int64_t N, int dtype, float* out, vo
 int colsum_chunks();
 int launch_colsum_partial(const void* X, int64_t R, int64_t N, int dtype, void* scratch, hipStream_t st);
 // split-K slabs of C[M,N] = A[K,M]^T B[K,N] into `slabs` ([S][M*N] f32); returns S through S_out
+int launch_gemm_nt_beside(const void* A, const void* Bt, const float* bias, float* C, int64_t M, int64_t N, int64_t K,
+                          int max_wgs, hipStream_t st);
 int launch_gemm_tn_slabs(const void* A, const void* B, float* slabs, int64_t M, int64_t N, int64_t K, int dtype,
                          hipStream_t st, int* S_out);
 

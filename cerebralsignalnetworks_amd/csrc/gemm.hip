@@ -398,9 +398,13 @@ gemm_nt_dma_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ Bt, 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const unsigned ntn = (unsigned)((N + 127) / 128);
-  const unsigned lid = xcd_remap(blockIdx.x, gridDim.x);
-  const int64_t m0 = (int64_t)(lid / ntn) * 128, n0 = (int64_t)(lid % ntn) * 128;
+  const unsigned ntiles = ntn * (unsigned)((M + 127) / 128);
   const int nk = (int)(K / 64);
+  // a grid smaller than the tile count walks the tiles (the "beside" form: few workgroups, one per CU, next to a
+  // persistent LSTM launch); pass `it` gives the workgroups of one XCD a contiguous range of logical tiles
+  for (unsigned lid = xcd_remap(blockIdx.x, gridDim.x); lid < ntiles; lid += gridDim.x) {
+  const int64_t m0 = (int64_t)(lid / ntn) * 128, n0 = (int64_t)(lid % ntn) * 128;
+  __syncthreads();     // every wave has left the previous tile's last LDS buffer
 
   // staging: instruction i of wave w fills rows [(4 i + w) 8, +8) of a tile (8 rows x 8 chunks = 1 KB);
   // lane -> row r = lane >> 3, LDS chunk position c = lane & 7 <- global chunk c ^ ((row >> 1) & 7)
@@ -492,6 +496,7 @@ gemm_nt_dma_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ Bt, 
       }
     }
   }
+  }   // tile loop
 }
 
 // NT, 256 x 128 output tile, 8 waves (4 along M x 2 along N, 64 x 64 outputs per wave), ring of NSTAGE LDS-DMA
@@ -512,9 +517,12 @@ gemm_nt_256_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ Bt, 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const unsigned ntn = (unsigned)((N + 127) / 128);
-  const unsigned lid = xcd_remap(blockIdx.x, gridDim.x);
-  const int64_t m0 = (int64_t)(lid / ntn) * 256, n0 = (int64_t)(lid % ntn) * 128;
+  const unsigned ntiles = ntn * (unsigned)((M + 255) / 256);
   const int nk = (int)(K / 64);
+  // a grid smaller than the tile count walks the tiles (the "beside" form, see gemm_nt_dma_kernel)
+  for (unsigned lid = xcd_remap(blockIdx.x, gridDim.x); lid < ntiles; lid += gridDim.x) {
+  const int64_t m0 = (int64_t)(lid / ntn) * 256, n0 = (int64_t)(lid % ntn) * 128;
+  __syncthreads();     // every wave has left the previous tile's last stage
 
   // staging: a 1 KB instruction fills 8 rows x 8 chunks; A has 32 of them per stage (4 per wave), B 16 (2 per
   // wave); lane -> row r = lane >> 3, LDS chunk position c = lane & 7 <- global chunk c ^ ((row >> 1) & 7)
@@ -625,6 +633,7 @@ gemm_nt_256_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ Bt, 
       }
     }
   }
+  }   // tile loop
 }
 
 // TN, 256 x 256 output tile, 8 waves (2 along M x 4 along N, 128 x 64 outputs per wave), LDS-DMA stages of
@@ -847,8 +856,8 @@ extern "C" int csn_gemm_nt(const void* A, const void* Bt, const float* bias, voi
   if (K % 64 == 0 && getenv("CSN_GEMM_NO_DMA") == nullptr) {
     static bool attr_done = false;
     if (!attr_done) {
-      if (int rc = ensure_dyn_lds(&gemm_nt_dma_kernel<bf16_t>, 65536)) return rc;
-      if (int rc = ensure_dyn_lds(&gemm_nt_dma_kernel<float>, 65536)) return rc;
+      if (int rc = ensure_dyn_lds(&gemm_nt_dma_kernel<bf16_t>, 98304)) return rc;
+      if (int rc = ensure_dyn_lds(&gemm_nt_dma_kernel<float>, 98304)) return rc;
       attr_done = true;
     }
     if (out_dtype == CSN_BF16)
@@ -869,6 +878,33 @@ extern "C" int csn_gemm_nt(const void* A, const void* Bt, const float* bias, voi
   CSN_LAUNCH_CHECK();
   return CSN_OK;
 }
+
+namespace csn {
+// NT GEMM on at most `max_wgs` workgroups, each alone on its CU (96 KB of LDS requested), walking the 128 x 128
+// tiles: runs beside a persistent LSTM launch on the CUs that launch leaves idle.  bf16 operands, K % 64 == 0.
+int launch_gemm_nt_beside(const void* A, const void* Bt, const float* bias, float* C, int64_t M, int64_t N, int64_t K,
+                          int max_wgs, hipStream_t st) {
+  CSN_REQUIRE(K % 64 == 0 && N % 4 == 0 && max_wgs >= 1, "launch_gemm_nt_beside: unsupported shape");
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (int rc = ensure_dyn_lds(&gemm_nt_256_kernel<float, 3>, 3 * 49152)) return rc;
+    if (int rc = ensure_dyn_lds(&gemm_nt_dma_kernel<float>, 98304)) return rc;
+    attr_done = true;
+  }
+  if (M >= 256 && N >= 128 && K >= 256) {
+    // 256 x 128 tiles, 8 waves, 144 KB of LDS: alone on a CU this kernel runs at twice the rate of the 4-wave one
+    const int64_t tiles = ((N + 127) / 128) * ((M + 255) / 256);
+    dim3 grid((unsigned)(tiles < max_wgs ? tiles : max_wgs));
+    gemm_nt_256_kernel<float, 3><<<grid, 512, 3 * 49152, st>>>((const bf16_t*)A, (const bf16_t*)Bt, bias, C, M, N, K, 0);
+  } else {
+    const int64_t tiles = ((N + 127) / 128) * ((M + 127) / 128);
+    dim3 grid((unsigned)(tiles < max_wgs ? tiles : max_wgs));
+    gemm_nt_dma_kernel<float><<<grid, 256, 98304, st>>>((const bf16_t*)A, (const bf16_t*)Bt, bias, C, M, N, K, 0);
+  }
+  CSN_LAUNCH_CHECK();
+  return CSN_OK;
+}
+}  // namespace csn
 
 extern "C" size_t csn_gemm_tn_scratch_bytes(int64_t M, int64_t N, int64_t K) {
   if (M <= 0 || N <= 0 || K <= 0) return 0;

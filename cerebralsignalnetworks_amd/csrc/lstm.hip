@@ -744,10 +744,16 @@ static int backward_il(const csnLstmDesc* d, const WsLayout& w, char* ws, const 
 }
 
 // Weight-stationary backward recurrence (lstm_bwd_persist.hip), grouped form: ONE launch per chunk diagonal
-// walks layer l backwards through reverse chunk (dg - (L-1-l)); the input gradient of a layer's chunk
-// (dx_l = dgates_l W_ih, the dy of the layer below) is a GEMM between two launches, and the weight / bias
-// gradients follow once the recurrence is complete -- all on the caller's stream: the persistent workgroups
-// own whole CUs, so nothing would overlap them anyway.
+// walks every layer in range backwards through one chunk.  The input gradient of a layer's chunk
+// (dx_l = dgates_l W_ih, the dy of the layer below) is a GEMM, and it runs INSIDE the next launch: the backward
+// kernel's groups occupy 24 of the 32 CUs of their XCD (24 slices of 32 units at H = 768), so the launch is
+// widened to 32 workgroups per XCD and the 8 extra ones (plus all workgroups of XCDs without a group) walk
+// the GEMM's tiles (gemm_beside.h).  Both of the GEMM's dependencies are then kernel boundaries: its input was
+// written by the launch before, its output is read by the launch after -- for which the layer below lags TWO
+// chunks: diagonal dg holds layer l at reverse chunk dg - 2 (L-1-l).  (A GEMM kernel on a second stream beside
+// the launch was measured too: the event waits between the streams cost ~30 us per launch, most of the gain.)
+// CSN_NO_BESIDE: lag one chunk, GEMM between two launches.
+// The weight / bias gradients follow once the recurrence is complete.
 static int backward_persist(const csnLstmDesc* d, const WsLayout& w, char* ws, const float* dy_last,
                             const float* dy_tm, float* const* dw_ih, float* const* dw_hh, float* const* db_ih,
                             float* const* db_hh, float* dx, hipStream_t st) {
@@ -755,7 +761,10 @@ static int backward_persist(const csnLstmDesc* d, const WsLayout& w, char* ws, c
   const int64_t G = 4 * (int64_t)H, TB = (int64_t)T * B;
   const int Bpad = (B + 63) / 64 * 64, MT = Bpad / 64;
   const int Cz = chunk_steps();
-  const int nch = (T + Cz - 1) / Cz, ndiag = nch + NL - 1;
+  const int nch = (T + Cz - 1) / Cz;
+  const bool beside = NL > 1 && NL <= 4 && bwd_persist_slices(H) <= 28 && G % 64 == 0 && getenv("CSN_NO_BESIDE") == nullptr;
+  const int lag = beside ? 2 : 1;
+  const int ndiag = nch + lag * (NL - 1);
   int rc;
   for (int l = 0; l < NL; ++l) {
     const LayerWs& L = w.layer[l];
@@ -769,13 +778,16 @@ static int backward_persist(const csnLstmDesc* d, const WsLayout& w, char* ws, c
   a.error_flag = (unsigned*)(ws + w.status);
   a.B = B; a.H = H; a.T = T; a.Bpad = Bpad; a.MT = MT;
   a.xcd_groups = 1;
+  a.grid_slices = 32;
   a.rotate = getenv("CSN_NO_ROTATE") == nullptr;
   int n_launch = 0;
+  BesideGemm pending[3];           // GEMMs of the chunks finished by the previous launch
+  int npending = 0;
   if ((rc = prof_mark(2, st))) return rc;
   for (int dg = 0; dg < ndiag; ++dg) {
     int lay[4], chk[4], ns = 0;
     for (int l = NL - 1; l >= 0; --l) {
-      const int c = dg - (NL - 1 - l);            // reverse chunk index of layer l on this diagonal
+      const int c = dg - lag * (NL - 1 - l);      // reverse chunk index of layer l on this diagonal
       if (c < 0 || c >= nch) continue;
       const LayerWs& L = w.layer[l];
       PersistBwdSlot& S = a.slot[ns];
@@ -800,6 +812,9 @@ static int backward_persist(const csnLstmDesc* d, const WsLayout& w, char* ws, c
       ++ns;
     }
     a.nslots = ns;
+    a.ngemm = npending;
+    for (int i = 0; i < npending; ++i) a.gemm[i] = pending[i];
+    npending = 0;
     a.agree = try_local ? (unsigned long long*)(ws + w.agree) + (size_t)dg * 8 : nullptr;
     if ((rc = prof_pair(1, false, st))) return rc;
     if ((rc = launch_bwd_persist(a, st))) return rc;
@@ -811,10 +826,14 @@ static int backward_persist(const csnLstmDesc* d, const WsLayout& w, char* ws, c
       // dx_l[chunk] = dgates_l[chunk] (interleaved K) * W_ih;  Bt = W_ih^T [I, 4H']
       const LayerWs& L = w.layer[l];
       const int t_hi = T - 1 - chk[i] * Cz, t_lo = t_hi - a.slot[i].nsteps + 1;
-      rc = csn_gemm_nt((const bf16_t*)(ws + L.dgates) + (size_t)t_lo * B * G, ws + L.wiht, nullptr,
-                       (float*)(ws + L.dx) + (size_t)t_lo * B * H, (int64_t)(t_hi - t_lo + 1) * B, H, G, CSN_BF16,
-                       CSN_F32, 0, (csnStream_t)st);
-      if (rc) return rc;
+      const bf16_t* Ag = (const bf16_t*)(ws + L.dgates) + (size_t)t_lo * B * G;
+      float* Cg = (float*)(ws + L.dx) + (size_t)t_lo * B * H;
+      const int64_t Mg = (int64_t)(t_hi - t_lo + 1) * B;
+      if (beside) {
+        pending[npending++] = BesideGemm{Ag, (const bf16_t*)(ws + L.wiht), Cg, (int)Mg, H, (int)G};
+      } else {
+        if ((rc = csn_gemm_nt(Ag, ws + L.wiht, nullptr, Cg, Mg, H, G, CSN_BF16, CSN_F32, 0, (csnStream_t)st))) return rc;
+      }
     }
   }
   if ((rc = prof_mark(3, st))) return rc;

@@ -19,6 +19,7 @@
 #include "csn_common.h"
 #include "lstm_cell_common.h"
 #include "lstm_cell_blk.h"
+#include "gemm_beside.h"
 
 #ifdef CSN_PSTAMPS
 __device__ unsigned long long g_bstamps[8];
@@ -71,7 +72,20 @@ __global__ void __launch_bounds__(256) lstm_bwd_persist_kernel(PersistBwdArgs a)
   if (a.xcd_groups) {
     grp = blockIdx.x & 7;
     slice = blockIdx.x >> 3;
-    if (grp >= a.nslots * MT) return;
+    const int ngroups = a.nslots * MT, gs = a.grid_slices;
+    if (grp >= ngroups || slice >= nslices) {
+      // no recurrence work for this workgroup: it walks the tiles of the launch's input-gradient GEMMs.  Workers of
+      // one XCD (equal blockIdx.x % 8) get consecutive indices, so they work on neighbouring tiles.
+      if (a.ngemm > 0) {
+        const int idle_here = gs - nslices;
+        const unsigned base = grp <= ngroups ? (unsigned)(grp * idle_here)
+                                             : (unsigned)(ngroups * idle_here + (grp - ngroups) * gs);
+        const unsigned worker = base + (unsigned)(grp < ngroups ? slice - nslices : slice);
+        const unsigned nworkers = (unsigned)(ngroups * idle_here + (8 - ngroups) * gs);
+        for (int i = 0; i < a.ngemm; ++i) beside_gemm_tiles(a.gemm[i], reinterpret_cast<char*>(red), worker, nworkers);
+      }
+      return;
+    }
   } else {
     grp = blockIdx.x / nslices;
     slice = blockIdx.x % nslices;
@@ -332,16 +346,25 @@ int bwd_persist_slices(int H) { return H / 32; }
 
 template <int NUT, int KS>
 static int launch_bwd_persist_t(const PersistBwdArgs& a, hipStream_t st) {
-  const size_t lds = (size_t)4 * 4 * NUT * 65 * sizeof(float4);
+  size_t lds = (size_t)4 * 4 * NUT * 65 * sizeof(float4);
   static bool attr_done = false;
   if (!attr_done) {
     CSN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_bwd_persist_kernel<NUT, KS>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBesideLdsBytes));
     attr_done = true;
   }
   const unsigned nslices = (unsigned)(a.H / (16 * NUT));
-  const unsigned grid = a.xcd_groups ? 8u * nslices : nslices * (unsigned)(a.MT * a.nslots);
-  lstm_bwd_persist_kernel<NUT, KS><<<dim3(grid), 256, lds, st>>>(a);
+  PersistBwdArgs b = a;
+  if (b.xcd_groups) {
+    if (b.ngemm > 0) {
+      lds = kBesideLdsBytes;                 // the GEMM workers' staging ring; also keeps every workgroup alone on its CU
+      if (b.grid_slices < (int)nslices) b.grid_slices = (int)nslices;
+    } else {
+      b.grid_slices = (int)nslices;
+    }
+  }
+  const unsigned grid = b.xcd_groups ? 8u * (unsigned)b.grid_slices : nslices * (unsigned)(b.MT * b.nslots);
+  lstm_bwd_persist_kernel<NUT, KS><<<dim3(grid), 256, lds, st>>>(b);
   CSN_LAUNCH_CHECK();
   return CSN_OK;
 }
@@ -351,6 +374,9 @@ int launch_bwd_persist(const PersistBwdArgs& a, hipStream_t st) {
   const int ns = bwd_persist_slices(a.H);
   CSN_REQUIRE(ns % 4 == 0 && ns <= kPersistFlagLine, "launch_bwd_persist: H=%d gives %d slices", a.H, ns);
   if (a.xcd_groups) CSN_REQUIRE(a.nslots * a.MT <= 8, "launch_bwd_persist: groups do not fit 8 XCDs");
+  CSN_REQUIRE(a.ngemm >= 0 && a.ngemm <= 3 && (a.ngemm == 0 || a.xcd_groups), "launch_bwd_persist: bad GEMM list");
+  for (int i = 0; i < a.ngemm; ++i)
+    CSN_REQUIRE(a.gemm[i].K % 64 == 0 && a.gemm[i].N % 4 == 0 && a.gemm[i].M > 0, "launch_bwd_persist: GEMM %d shape", i);
   switch (a.H) {
     case 768: return launch_bwd_persist_t<2, 24>(a, st);
     case 512: return launch_bwd_persist_t<2, 16>(a, st);

@@ -86,9 +86,20 @@ struct PersistBwdSlot {
   unsigned* flags;         // [T][MT][kPersistFlagLine], zeroed per backward
   int t_hi, nsteps;        // steps t_hi, t_hi - 1, ..., t_hi - nsteps + 1
 };
+// C[M,N] (f32) = A[M,K] * Bt[N,K]^T, bf16 operands: run by the workgroups of a backward launch that have no
+// recurrence work (gemm_beside.h)
+struct BesideGemm {
+  const bf16_t* A;
+  const bf16_t* Bt;
+  float* C;
+  int M, N, K;
+};
 struct PersistBwdArgs {
   PersistBwdSlot slot[4];
   int nslots;
+  BesideGemm gemm[3];      // input-gradient GEMMs of the chunks the layers above finished one launch ago
+  int ngemm;
+  int grid_slices;         // xcd_groups: the grid is 8 * grid_slices workgroups (>= slices per group)
   int xcd_groups;
   int rotate;              // != 0: each workgroup walks the k-blocks from its own offset (changes the summation order)
   unsigned long long* agree;
