@@ -476,7 +476,10 @@ def test_fast_path_matches_oracle_and_v1(cuda, B, T, C, H, L, chunk):
     slow = _run_lstm(p, x, dy_all, dy_last, C, H, L, torch.bfloat16, cuda, {"CSN_CELL_V1": "1"})
     # the schedules / hand-off forms of the default path compute the same bits: single stream instead of side
     # streams, the placement-independent hand-off instead of the L2-local one
-    for name, other in (("serial", run(CSN_NO_SIDE_STREAM="1")), ("anyplace", run(CSN_NO_XCD_LOCAL="1"))):
+    # (nobeside: the input-gradient GEMMs as kernels of their own between two backward launches, layers one chunk
+    # apart, instead of on the idle workgroups of the next launch with the layers two chunks apart)
+    for name, other in (("serial", run(CSN_NO_SIDE_STREAM="1")), ("anyplace", run(CSN_NO_XCD_LOCAL="1")),
+                        ("nobeside", run(CSN_NO_BESIDE="1"))):
         for k in fast:
             _assert_same_bits(fast[k], other[k], f"{name}: {k}")
     # with every workgroup walking K in the same order (the default rotates the walk per workgroup, which only
