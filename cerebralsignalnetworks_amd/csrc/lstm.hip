@@ -42,7 +42,7 @@ struct LayerWs {
 };
 struct WsLayout {
   LayerWs layer[8];
-  size_t x_c, x_blk, wih0_blk, dy_tm, tn_scratch, colsum, status, agree, total;
+  size_t x_c, x_blk, wih0_blk, dy_tm, tn_scratch, colsum, status, agree, zeros_bh, total;
   bool fuse_x;
   bool il, persist, persist_bwd;
 };
@@ -110,6 +110,7 @@ static WsLayout make_layout(const csnLstmDesc& d, int training) {
     w.x_blk = take((size_t)d.T * Bpad * d.I * 2);
     w.wih0_blk = take(G * d.I * 2);
   }
+  if (w.persist_bwd) w.zeros_bh = take((size_t)d.B * H * 4);
   if (w.persist) w.agree = take(((size_t)d.T + 8) * 8 * sizeof(unsigned long long));   // 8 words per launch
   if (training) {
     w.dy_tm = take(TB * H * 4);
@@ -773,6 +774,7 @@ static int backward_persist(const csnLstmDesc* d, const WsLayout& w, char* ws, c
   }
   const bool try_local = getenv("CSN_NO_XCD_LOCAL") == nullptr;
   if (try_local) CSN_HIP_CHECK(hipMemsetAsync(ws + w.agree, 0, (size_t)ndiag * 8 * sizeof(unsigned long long), st));
+  CSN_HIP_CHECK(hipMemsetAsync(ws + w.zeros_bh, 0, (size_t)B * H * 4, st));
 
   PersistBwdArgs a{};
   a.error_flag = (unsigned*)(ws + w.status);
@@ -801,6 +803,7 @@ static int backward_persist(const csnLstmDesc* d, const WsLayout& w, char* ws, c
         S.dy = (const float*)(ws + w.layer[l + 1].dx);
         S.dy_last = nullptr;
       }
+      S.zeros = (const float*)(ws + w.zeros_bh);
       S.dc_carry = (float*)(ws + L.dc_carry);
       S.dgates = (bf16_t*)(ws + L.dgates);
       S.dg_blk_all = (bf16_t*)(ws + L.dg_blk_all);

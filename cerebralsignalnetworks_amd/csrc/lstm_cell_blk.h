@@ -80,6 +80,7 @@ struct PersistBwdSlot {
   const float* c_all;      // [T+1, B, H]  (slot t+1 = c_t)
   const float* dy;         // [T, B, H] gradient w.r.t. this layer's output, or null
   const float* dy_last;    // [B, H] added at t = T-1 when dy is null, or null
+  const float* zeros;      // [B, H] of zeros: what a step reads when it has no incoming gradient
   float* dc_carry;         // [B, H] carried dc, in/out across launches
   bf16_t* dgates;          // [T, B, 4H] interleaved, row-major (GEMM operand)
   bf16_t* dg_blk_all;      // [T][Bpad * 4H] fragment-major slabs (slot t = dgates_t); never reused in a backward

@@ -42,12 +42,15 @@
 #include "lstm_cell_blk.h"
 
 #ifdef CSN_PSTAMPS
+#ifndef CSN_STAMP_BLOCK
+#define CSN_STAMP_BLOCK 11     // group 3 (layer 0 at cfg2), slice 1; 15 = group 7 (layer 1)
+#endif
 // diagnostic build only (tools/persist_bench.hip): per-phase wall-clock sums of workgroup (0,0)
 __device__ unsigned long long g_pstamps[8];
 #define CSN_PSTAMP(i)                                                          \
   do {                                                                         \
     __builtin_amdgcn_sched_barrier(0);                                         \
-    if (tid == 0 && blockIdx.x == 11) {                                        \
+    if (tid == 0 && blockIdx.x == CSN_STAMP_BLOCK) {                           \
       const unsigned long long now_ = wall_clock64();                          \
       atomicAdd(&g_pstamps[i], now_ - last_);                                  \
       last_ = now_;                                                            \

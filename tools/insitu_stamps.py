@@ -3,7 +3,7 @@ import ctypes, os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ["CSN_LIB_PATH"] = os.path.join(ROOT, "cerebralsignalnetworks_amd", "lib", "libcsn_hip_diag.so")
+os.environ["CSN_LIB_PATH"] = os.path.join(ROOT, "cerebralsignalnetworks_amd", "lib", os.environ.get("CSN_DIAG_LIB", "libcsn_hip_diag.so"))
 from cerebralsignalnetworks_amd import cabi, Model, EEGFilters  # noqa: E402
 from cerebralsignalnetworks_amd.trainer import DistillTrainer  # noqa: E402
 
