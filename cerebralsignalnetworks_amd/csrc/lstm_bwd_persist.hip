@@ -70,6 +70,9 @@ __global__ void __launch_bounds__(256) lstm_bwd_persist_kernel(PersistBwdArgs a)
   extern __shared__ __attribute__((aligned(16))) float4 red[];   // [4][NT][65]
   const int B = a.B, H = a.H, MT = a.MT, T = a.T;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef CSN_PSTAMPS
+  const unsigned long long t_entry_ = wall_clock64();
+#endif
   const int nslices = H / (16 * NUT);
   int grp, slice;
   if (a.xcd_groups) {
@@ -193,6 +196,7 @@ __global__ void __launch_bounds__(256) lstm_bwd_persist_kernel(PersistBwdArgs a)
   request_saved(t_hi);
 #ifdef CSN_PSTAMPS
   unsigned long long last_ = wall_clock64();
+  if (tid == 0 && blockIdx.x == CSN_STAMP_BLOCK) atomicAdd(&g_bstamps[6], last_ - t_entry_);   // prologue of this launch
 #endif
 
   for (int s = 0; s < nsteps; ++s) {

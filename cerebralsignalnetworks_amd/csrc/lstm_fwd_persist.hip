@@ -110,6 +110,9 @@ __global__ void __launch_bounds__(256) lstm_fwd_persist_kernel(PersistFwdArgs a)
   extern __shared__ __attribute__((aligned(16))) float4 red[];   // [4][NT][65], then [NQ][4] bias
   const int B = a.B, H = a.H, MT = a.MT;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef CSN_PSTAMPS
+  const unsigned long long t_entry_ = wall_clock64();
+#endif
   const int nslices = H / (4 * NQ);
   // hand-off group = (slot, M-tile); a workgroup's place in it = its slice of the hidden units
   int grp, slice;
@@ -216,6 +219,7 @@ __global__ void __launch_bounds__(256) lstm_fwd_persist_kernel(PersistFwdArgs a)
       __builtin_amdgcn_make_buffer_rsrc((void*)h_blk_all, 0, (int)((size_t)(a.T + 1) * slab * 2), 0x00020000);
 #ifdef CSN_PSTAMPS
   unsigned long long last_ = wall_clock64();
+  if (tid == 0 && blockIdx.x == CSN_STAMP_BLOCK) atomicAdd(&g_pstamps[6], last_ - t_entry_);   // prologue of this launch
 #endif
 
   auto request_input = [&](int t) {

@@ -23,5 +23,5 @@ for it in range(4):
     for name, fn in (("fwd", lib.csn_debug_read_pstamps), ("bwd", lib.csn_debug_read_bstamps)):
         fn(buf)
         per = [buf[i] * 0.01 / T for i in range(6)]
-        print("step %d %s per-step us: wait %.2f | loads+mfma %.2f | lds %.2f | epilogue %.2f | drain %.2f | signal %.2f | sum %.2f"
-              % (it, name, *per, sum(per)), flush=True)
+        print("step %d %s per-step us: wait %.2f | loads+mfma %.2f | lds %.2f | epilogue %.2f | drain %.2f | signal %.2f | sum %.2f | prologue per launch %.1f us"
+              % (it, name, *per, sum(per), buf[6] * 0.01 / 16), flush=True)
