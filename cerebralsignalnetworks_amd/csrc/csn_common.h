@@ -77,6 +77,6 @@ int launch_colsum_partial(const void* X, int64_t R, int64_t N, int dtype, void* 
 int launch_gemm_nt_beside(const void* A, const void* Bt, const float* bias, float* C, int64_t M, int64_t N, int64_t K,
                           int max_wgs, hipStream_t st);
 int launch_gemm_tn_slabs(const void* A, const void* B, float* slabs, int64_t M, int64_t N, int64_t K, int dtype,
-                         hipStream_t st, int* S_out);
+                         hipStream_t st, int* S_out, float* colsum, int* colsum_done);
 
 }  // namespace csn

@@ -673,7 +673,7 @@ __device__ __forceinline__ bf16x8 tr_read_pair(unsigned addr) {
 template <int NSTAGE>
 __global__ void __launch_bounds__(512)
 gemm_tn_256_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ Bm, float* __restrict__ slabs,
-                   int64_t M, int64_t N, int64_t K, int64_t k_per_split) {
+                   int64_t M, int64_t N, int64_t K, int64_t k_per_split, float* __restrict__ colsum) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];  // NSTAGE x (A 16 KB + B 16 KB)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 2, wn = wave & 3;
@@ -716,6 +716,13 @@ gemm_tn_256_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ Bm, 
   for (int i = 0; i < 8; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // optional column sums of A (the bias gradient: sum over the contraction rows of dgates): the waves that hold
+  // the first 64 output columns of the first column tile multiply their A fragments by a fragment of ones too
+  const bool do_colsum = colsum != nullptr && n0 == 0 && wn == 0;
+  const bf16x8 ones = {(bf16_t)1.0f, (bf16_t)1.0f, (bf16_t)1.0f, (bf16_t)1.0f, (bf16_t)1.0f, (bf16_t)1.0f, (bf16_t)1.0f, (bf16_t)1.0f};
+  f32x4 acc_cs[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc_cs[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   // byte address (inside a stage) of this lane's first ds_read_b64_tr_b16 of every fragment; the second one
   // (k-rows + 4) is 2048 bytes further
@@ -763,7 +770,16 @@ gemm_tn_256_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ Bm, 
 #pragma unroll
       for (int j = 0; j < 4; ++j)
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+      if (do_colsum) acc_cs[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[i], acc_cs[i], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+
+  if (do_colsum && (lane >> 4) == 0) {       // D[n][m]: every row n holds the same sum; lanes 0..15 write column m
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int64_t m = m0 + wm * 128 + i * 16 + (lane & 15);
+      if (m < M) colsum[(int64_t)zsplit * M + m] = acc_cs[i][0];
     }
   }
 
@@ -913,8 +929,11 @@ extern "C" size_t csn_gemm_tn_scratch_bytes(int64_t M, int64_t N, int64_t K) {
 }
 
 namespace csn {
+// colsum (optional): device buffer of at least 64 * M floats; if the kernel that runs can produce the column sums
+// of A on the way (one partial row of M values per K split), *colsum_done is set to 1.
 int launch_gemm_tn_slabs(const void* A, const void* B, float* slabs, int64_t M, int64_t N, int64_t K, int dtype,
-                         hipStream_t st, int* S_out) {
+                         hipStream_t st, int* S_out, float* colsum, int* colsum_done) {
+  if (colsum_done) *colsum_done = 0;
   const bool aligned16 = ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15) == 0;
   if (dtype == CSN_BF16 && (M % 8 == 0) && (N % 8 == 0) && aligned16 && tn_use_256(M, N, K)) {
     const int S2 = tn_splits_256(M, N, K);
@@ -931,9 +950,10 @@ int launch_gemm_tn_slabs(const void* A, const void* B, float* slabs, int64_t M, 
     dim3 grid((unsigned)(((N + 255) / 256) * ((M + 255) / 256) * S2));
     const char* ns = getenv("CSN_TN_STAGES");
     const int nst = ns ? atoi(ns) : 4;
-    if (nst == 3) gemm_tn_256_kernel<3><<<grid, 512, 3 * 32768, st>>>((const bf16_t*)A, (const bf16_t*)B, slabs, M, N, K, kper2);
-    else if (nst == 4) gemm_tn_256_kernel<4><<<grid, 512, 4 * 32768, st>>>((const bf16_t*)A, (const bf16_t*)B, slabs, M, N, K, kper2);
-    else gemm_tn_256_kernel<5><<<grid, 512, 5 * 32768, st>>>((const bf16_t*)A, (const bf16_t*)B, slabs, M, N, K, kper2);
+    if (nst == 3) gemm_tn_256_kernel<3><<<grid, 512, 3 * 32768, st>>>((const bf16_t*)A, (const bf16_t*)B, slabs, M, N, K, kper2, colsum);
+    else if (nst == 4) gemm_tn_256_kernel<4><<<grid, 512, 4 * 32768, st>>>((const bf16_t*)A, (const bf16_t*)B, slabs, M, N, K, kper2, colsum);
+    else gemm_tn_256_kernel<5><<<grid, 512, 5 * 32768, st>>>((const bf16_t*)A, (const bf16_t*)B, slabs, M, N, K, kper2, colsum);
+    if (colsum && colsum_done) *colsum_done = 1;
     CSN_LAUNCH_CHECK();
     return CSN_OK;
   }
@@ -965,6 +985,6 @@ extern "C" int csn_gemm_tn(const void* A, const void* B, float* C, int64_t M, in
   CSN_REQUIRE(dtype == CSN_F32 || dtype == CSN_BF16, "csn_gemm_tn: bad dtype %d", dtype);
   hipStream_t st = as_stream(stream);
   int S = 1;
-  if (int rc = launch_gemm_tn_slabs(A, B, (float*)scratch, M, N, K, dtype, st, &S)) return rc;
+  if (int rc = launch_gemm_tn_slabs(A, B, (float*)scratch, M, N, K, dtype, st, &S, nullptr, nullptr)) return rc;
   return launch_reduce_slabs((const float*)scratch, M * N, S, C, M * N, 0, st);
 }

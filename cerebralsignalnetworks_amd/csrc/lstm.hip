@@ -657,12 +657,18 @@ static int backward_il(const csnLstmDesc* d, const WsLayout& w, char* ws, const 
                              : (const void*)((const bf16_t*)(ws + w.layer[l - 1].h_all) + (size_t)B * H);
     float* slabs = (float*)(ws + w.tn_scratch);
     int S = 1, r;
-    if ((r = launch_gemm_tn_slabs(ws + L.dgates, ws + L.h_all, slabs, G, H, TB, CSN_BF16, side, &S))) return r;
+    int cs_done = 0, S_cs = 1;
+    if ((r = launch_gemm_tn_slabs(ws + L.dgates, ws + L.h_all, slabs, G, H, TB, CSN_BF16, side, &S, (float*)(ws + w.colsum), &cs_done))) return r;
+    S_cs = S;
     if ((r = launch_reduce_slabs_unperm(slabs, G * H, S, H, H, dw_hh[l], side))) return r;
-    if ((r = launch_gemm_tn_slabs(ws + L.dgates, inp, slabs, G, I, TB, CSN_BF16, side, &S))) return r;
+    if ((r = launch_gemm_tn_slabs(ws + L.dgates, inp, slabs, G, I, TB, CSN_BF16, side, &S, nullptr, nullptr))) return r;
     if ((r = launch_reduce_slabs_unperm(slabs, G * I, S, H, I, dw_ih[l], side))) return r;
-    if ((r = launch_colsum_partial(ws + L.dgates, TB, G, CSN_BF16, ws + w.colsum, side))) return r;
-    if ((r = launch_reduce_slabs_unperm((const float*)(ws + w.colsum), G, colsum_chunks(), H, 1, db_ih[l], side)))
+    // bias gradient = column sums of dgates: partial sums come out of the dW_hh GEMM when its kernel provides them
+    if (!cs_done) {
+      if ((r = launch_colsum_partial(ws + L.dgates, TB, G, CSN_BF16, ws + w.colsum, side))) return r;
+      S_cs = colsum_chunks();
+    }
+    if ((r = launch_reduce_slabs_unperm((const float*)(ws + w.colsum), G, S_cs, H, 1, db_ih[l], side)))
       return r;
     CSN_HIP_CHECK(hipMemcpyAsync(db_hh[l], db_ih[l], (size_t)G * 4, hipMemcpyDeviceToDevice, side));
     return CSN_OK;
@@ -859,12 +865,18 @@ static int backward_persist(const csnLstmDesc* d, const WsLayout& w, char* ws, c
                              : (const void*)((const bf16_t*)(ws + w.layer[l - 1].h_all) + (size_t)B * H);
     float* slabs = (float*)(ws + w.tn_scratch);
     int S = 1;
-    if ((rc = launch_gemm_tn_slabs(ws + L.dgates, ws + L.h_all, slabs, G, H, TB, CSN_BF16, st, &S))) return rc;
+    int cs_done = 0, S_cs = 1;
+    if ((rc = launch_gemm_tn_slabs(ws + L.dgates, ws + L.h_all, slabs, G, H, TB, CSN_BF16, st, &S, (float*)(ws + w.colsum), &cs_done))) return rc;
+    S_cs = S;
     if ((rc = launch_reduce_slabs_unperm(slabs, G * H, S, H, H, dw_hh[l], st))) return rc;
-    if ((rc = launch_gemm_tn_slabs(ws + L.dgates, inp, slabs, G, I, TB, CSN_BF16, st, &S))) return rc;
+    if ((rc = launch_gemm_tn_slabs(ws + L.dgates, inp, slabs, G, I, TB, CSN_BF16, st, &S, nullptr, nullptr))) return rc;
     if ((rc = launch_reduce_slabs_unperm(slabs, G * I, S, H, I, dw_ih[l], st))) return rc;
-    if ((rc = launch_colsum_partial(ws + L.dgates, TB, G, CSN_BF16, ws + w.colsum, st))) return rc;
-    if ((rc = launch_reduce_slabs_unperm((const float*)(ws + w.colsum), G, colsum_chunks(), H, 1, db_ih[l], st)))
+    // bias gradient = column sums of dgates: partial sums come out of the dW_hh GEMM when its kernel provides them
+    if (!cs_done) {
+      if ((rc = launch_colsum_partial(ws + L.dgates, TB, G, CSN_BF16, ws + w.colsum, st))) return rc;
+      S_cs = colsum_chunks();
+    }
+    if ((rc = launch_reduce_slabs_unperm((const float*)(ws + w.colsum), G, S_cs, H, 1, db_ih[l], st)))
       return rc;
     CSN_HIP_CHECK(hipMemcpyAsync(db_hh[l], db_ih[l], (size_t)G * 4, hipMemcpyDeviceToDevice, st));
   }

@@ -457,7 +457,9 @@ def _rel(a, b):
                                              (64, 20, 32, 256, 1, "32"), (5, 9, 8, 384, 2, "4"),
                                              (6, 44, 128, 1024, 2, "16"),      # cfg4 width (Spampinato split: H=1024)
                                              (40, 24, 128, 128, 4, "8"),       # 4 layers (TrainSpampinato.py:368)
-                                             (130, 33, 16, 512, 2, "32")])
+                                             (130, 33, 16, 512, 2, "32"),
+                                             # T*B >= 8192 rows: 256 x 256 weight-gradient kernel + fused bias sums
+                                             (64, 130, 32, 256, 2, "32")])
 def test_fast_path_matches_oracle_and_v1(cuda, B, T, C, H, L, chunk):
     rng = np.random.default_rng(B * T + H)
     p = lstm.init_params(C, H, L, 8, None, seed=5)
