@@ -158,6 +158,13 @@ def main():
             flops_per_launch = 2.0 * B * 4 * H * H * cells_per_launch
             bytes_per_cell = B * H * (24.0 if dom == "bwd" else 30.0)
             bytes_per_launch = bytes_per_cell * cells_per_launch
+            beside = dom == "bwd" and persist["bwd"] and L > 1 and not os.environ.get("CSN_NO_BESIDE")
+            if beside:
+                # the backward launches also carry the input-gradient GEMMs of the layers above layer 0 on their idle
+                # workgroups: dx[T*B, H] = dgates[T*B, 4H] W_ih -> 2*T*B*4H*H flops, read dgates bf16, write dx f32
+                n_l = max(1, pr["bwd_launches"])
+                flops_per_launch += (L - 1) * 2.0 * T * B * 4 * H * H / n_l
+                bytes_per_launch += (L - 1) * T * B * (4 * H * 2.0 + H * 4.0) / n_l
             t_launch = us[dom] * 1e-6
             ach_tf = flops_per_launch / t_launch / 1e12
             ach_gb = bytes_per_launch / t_launch / 1e9
@@ -167,7 +174,7 @@ def main():
             try:
                 if (B, C, T, H, L) != (256, 128, 500, 768, 2):
                     raise KeyError("PMC passes were collected for cfg2 only")
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_d_pmc_traffic.json")))
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_e_pmc_traffic.json")))
                 traffic = pmc["kernels"][kname]["hbm_bytes_per_launch_corrected"]
             except (OSError, KeyError, ValueError):
                 pass
@@ -181,7 +188,7 @@ def main():
                                                   "achieved": ach_tf if hbm_bound else ach_gb,
                                                   "frac": (ach_tf / peak) if hbm_bound else (ach_gb / HBM_PEAK_GBS)},
                                "us_per_launch": us, "launches": {k: pr[k + "_launches"] for k in ("fwd", "bwd")},
-                               "cells_per_launch": cells_per_launch,
+                               "cells_per_launch": cells_per_launch, "input_gradient_gemm_in_launch": bool(beside),
                                "note": "recurrent GEMM chain with one hand-off between workgroups per timestep; neither "
                                        "roofline binds: the step is paced by the per-step operand stream from L2 and "
                                        "the hand-off latency (DESIGN.md section 3)"}
