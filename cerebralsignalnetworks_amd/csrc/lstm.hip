@@ -416,8 +416,10 @@ static int forward_il(const csnLstmDesc* d, const WsLayout& w, char* ws, const f
       // W_hh^T [H rows = unit][k' = 4u'+g]: element (u, k') = W_hh[std_row(k')][u]
       if ((rc = launch_blockify(w_hh[l], 1, H, H, G, 0, 1, H, ws + L.whht_blk, st))) return rc;
     }
-    CSN_HIP_CHECK(hipMemsetAsync(ws + L.hblk[0], 0, Bpad * H * 2, st));
-    CSN_HIP_CHECK(hipMemsetAsync(ws + L.hblk[1], 0, Bpad * H * 2, st));
+    if (!w.persist) {       // ping-pong hand-off buffers of the per-timestep launches
+      CSN_HIP_CHECK(hipMemsetAsync(ws + L.hblk[0], 0, Bpad * H * 2, st));
+      CSN_HIP_CHECK(hipMemsetAsync(ws + L.hblk[1], 0, Bpad * H * 2, st));
+    }
     CSN_HIP_CHECK(hipMemsetAsync(ws + L.h_all, 0, (size_t)B * H * 2, st));
     CSN_HIP_CHECK(hipMemsetAsync(ws + L.c_all, 0, (size_t)B * H * 4, st));
   }

@@ -392,8 +392,22 @@ __global__ void __launch_bounds__(256) lstm_fwd_persist_kernel(PersistFwdArgs a)
   }
 }
 
+// The weight-stationary kernels place one workgroup per CU and need all of a launch co-resident: they are used
+// only on a full MI355X (256 CUs; smaller partitions take the per-timestep launches).
+static bool device_has_256_cus() {
+  static int cached[16] = {0};               // 0 unknown, 1 yes, -1 no
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return false;
+  if (cached[dev] == 0) {
+    int cus = 0;
+    cached[dev] = (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus >= 256) ? 1 : -1;
+  }
+  return cached[dev] == 1;
+}
+
 bool fwd_persist_supported(int B, int H, int dtype) {
   if (dtype != CSN_BF16 || H % 128 != 0 || getenv("CSN_NO_PERSIST") != nullptr) return false;
+  if (!device_has_256_cus()) return false;
   const int nq = (H % 24 == 0) ? 6 : 8, ks = H / 128;
   const bool shape = (nq == 6 && (ks == 6 || ks == 3)) || (nq == 8 && (ks == 4 || ks == 2 || ks == 1));
   // all workgroups of a launch must be co-resident: one per CU, and two layers run side by side
