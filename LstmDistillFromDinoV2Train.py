@@ -151,6 +151,7 @@ def main(argv=None):
         losses = []
         for b in batches(train_idx, EPOCH, True):
             losses.append(trainer.train_step(dataset.eeg_all[b], dataset.features_all[b], dataset.labels_dev[b], EPOCH))
+        trainer.check_device_status()      # per epoch: a timed-out in-kernel hand-off must not pass silently
         epoch_loss = float(torch.stack(losses).mean().item())                    # one sync per epoch, not per step
         if EPOCH % FLAGS.validation_frequency == 0 and EPOCH > 0:
             model.eval()

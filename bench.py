@@ -121,6 +121,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     final_loss = float(loss.item())
+    trainer.check_device_status()       # a timed-out in-kernel hand-off would invalidate the run: fail loudly
     log(f"timed region done: {elapsed:.3f}s for {args.steps} steps; losses " +
         " ".join(f"{float(l):.4f}" for l in step_losses))
 

@@ -132,6 +132,18 @@ class DistillTrainer:
         self.opt.step()
         return loss.detach()
 
+    def check_device_status(self):
+        """Blocking: raises if an in-kernel hand-off of a weight-stationary LSTM kernel ever timed out (the
+        results of that step are then invalid).  Call it at epoch ends / after a timed region, not per step."""
+        from .lstm_model import HipLSTM
+        torch.cuda.synchronize()
+        for mod in self.model.modules():
+            if isinstance(mod, HipLSTM):
+                for plan in mod.all_plans():
+                    if plan.status() != 0:
+                        raise RuntimeError("libcsn_hip: a bounded in-kernel wait of the LSTM recurrence timed out "
+                                           "(is another process using this GPU's CUs?); results are invalid")
+
     @torch.no_grad()
     def embed_all(self, eeg_all, batch):
         self.model.eval()
