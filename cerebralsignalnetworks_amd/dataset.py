@@ -172,6 +172,41 @@ class EEGDataset(Dataset):
         self.image_features_extracted = True
 
     @torch.no_grad()
+    def transformEEGDataToChannelWiseNorm(self, compat_stale_index=False):
+        """Class-wise, channel-wise normalisation of the resident segments (PerilsEEGDataset.py:464-507): per class
+        and channel, (x - mean of the per-segment means) / (mean of the per-segment stds, ddof 0), statistics over
+        the [time_low:time_high] window.  One pass on the device instead of the reference's N x C Python loop.
+
+        compat_stale_index=True reproduces what the reference's code actually leaves behind (it stores every
+        result into the LAST record -- ``self.subsetData[i]`` with a stale ``i``, :507 -- and indexes the
+        channel-first record as ``eeg[:, ch]``, :503-506): only record N-1 changes."""
+        x = self.eeg_all                                                # [N, C, T]
+        N, C, T = x.shape
+        labels = self.labels_dev.long()
+        seg_mean = x.mean(dim=2)                                        # [N, C]
+        seg_std = x.std(dim=2, unbiased=False)
+        K = int(labels.max().item()) + 1
+        count = torch.zeros(K, device=x.device).index_add_(0, labels, torch.ones(N, device=x.device)).clamp_(min=1)
+        cls_mean = torch.zeros(K, C, device=x.device).index_add_(0, labels, seg_mean) / count[:, None]
+        cls_std = torch.zeros(K, C, device=x.device).index_add_(0, labels, seg_std) / count[:, None]
+        if not compat_stale_index:
+            self.eeg_all = ((x - cls_mean[labels][:, :, None]) / cls_std[labels][:, :, None]).contiguous()
+            return
+        seen = []
+        for k in self.labels.tolist():                                   # classes in order of first appearance
+            if k not in seen:
+                seen.append(k)
+        last_class = seen[-1]
+        last_idx = int((self.labels == last_class).nonzero()[-1])
+        rec = x[last_idx].clone()
+        lo = max(0, self.time_low)
+        chs = torch.arange(C, device=x.device)
+        cols = chs - lo
+        ok = (cols >= 0) & (cols < T)
+        rec[:, cols[ok]] = (rec[:, cols[ok]] - cls_mean[last_class][chs[ok]][None, :]) / cls_std[last_class][chs[ok]][None, :]
+        self.eeg_all[N - 1] = rec
+
+    @torch.no_grad()
     def transformEEGDataLSTMByList(self, model, data_loader):
         """Embeds a loader's EEG with ``model``; returns (list of np rows, list of label dicts).
         ``compat_label_bug`` reproduces the reference's batch-local label lookup (:336-338)."""

@@ -149,3 +149,50 @@ def synthetic_eeg(n, channels=128, samples=500, fs=1000.0, freq=40.0, amp=0.5, s
     t = np.arange(samples) / fs
     x = rng.standard_normal((n, channels, samples)) + amp * np.sin(2 * np.pi * freq * t)
     return x.astype(np.float32)
+
+
+def classwise_channel_norm(eeg_nct, class_ids, time_low=0, compat_stale_index=False):
+    """Class-wise, channel-wise normalisation of a dataset, restating
+    /root/reference/utils/PerilsEEGDataset.py:464-507 (``transformEEGDataToChannelWiseNorm``).
+
+    Statistics, as the reference computes them: per class (in order of first appearance), per channel, the mean
+    over that class's segments of the per-segment mean and of the per-segment numpy std (ddof 0) over the time
+    window ``__getitem__`` returns.  ``eeg_nct`` here IS that window (``[N, C, T]``, already sliced at
+    ``time_low``), so normalising it element-wise equals slicing the reference's normalised full-length record.
+
+    compat_stale_index=False: what the function is written to do -- every segment of the class normalised with
+    its class's per-channel statistics.
+    compat_stale_index=True: what the reference's code does -- (a) ``:507`` stores into ``self.subsetData[i]`` with
+    ``i`` left over from the first loop (= N-1), so only the LAST record is ever overwritten, each time with the
+    transformed copy of the record being visited; (b) the record is stored channel-first ``[C, T_raw]`` but
+    ``:503-506`` index it as ``eeg[:, ch]``, so "channel" ch's statistics are applied to the raw TIME sample ch of
+    every channel.  The final state is: record N-1 = that transform of the last record of the last class.
+    """
+    x = np.array(eeg_nct, dtype=np.float32, copy=True)
+    N, C, T = x.shape
+    order = []
+    for k in class_ids:
+        if int(k) not in order:
+            order.append(int(k))
+    out = x.copy()
+    for k in order:
+        idx = [i for i in range(N) if int(class_ids[i]) == k]
+        means = np.array([[x[i, c].mean() for c in range(C)] for i in idx], dtype=np.float32)
+        stds = np.array([[x[i, c].std() for c in range(C)] for i in idx], dtype=np.float32)
+        mean_mean, mean_std = means.mean(axis=0), stds.mean(axis=0)
+        for i in idx:
+            if not compat_stale_index:
+                out[i] = (x[i] - mean_mean[:, None]) / mean_std[:, None]
+            else:
+                rec = x[i].copy()                       # [C, T] = raw columns time_low .. time_low + T - 1
+                for ch in range(C):
+                    col = ch - time_low
+                    if 0 <= col < T:
+                        rec[:, col] = (rec[:, col] - mean_mean[ch]) / mean_std[ch]
+                out[N - 1] = rec
+    if compat_stale_index:
+        keep = out[N - 1].copy()
+        out = x.copy()
+        out[N - 1] = keep
+    return out
+

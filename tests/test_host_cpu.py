@@ -125,3 +125,28 @@ def test_flat_gradient_allreduce_two_process_gloo():
     for r in range(world):
         np.testing.assert_allclose(out[r], want, rtol=1e-6, atol=1e-7)
     np.testing.assert_array_equal(out[0], out[1])
+
+
+def test_classwise_channel_norm_matches_oracle_both_modes():
+    """PerilsEEGDataset.transformEEGDataToChannelWiseNorm (:464-507): the intended normalisation and, behind a
+    switch, the state the reference's stale-index / transposed-index code actually leaves."""
+    import torch
+    from cerebralsignalnetworks_amd.dataset import EEGDataset
+    from oracle import eeg_filter
+    for compat in (False, True):
+        ds = EEGDataset(synthetic=37, synthetic_channels=24, synthetic_samples=90, n_classes=5, time_low=10,
+                        time_high=80, seed=3, device=torch.device("cpu"))
+        before = ds.eeg_all.clone().numpy()
+        want = eeg_filter.classwise_channel_norm(before, ds.labels.numpy(), time_low=10, compat_stale_index=compat)
+        ds.transformEEGDataToChannelWiseNorm(compat_stale_index=compat)
+        got = ds.eeg_all.numpy()
+        np.testing.assert_allclose(got, want, rtol=2e-5, atol=2e-5)
+        if compat:                                   # only the last record changed
+            np.testing.assert_array_equal(got[:-1], before[:-1])
+            assert np.abs(got[-1] - before[-1]).max() > 1e-3
+        else:                                        # every class/channel: mean of segment means 0, mean of stds 1
+            for k in set(ds.labels.tolist()):
+                sel = got[ds.labels.numpy() == k]
+                np.testing.assert_allclose(sel.mean(axis=2).mean(axis=0), 0.0, atol=1e-5)
+                np.testing.assert_allclose(sel.std(axis=2).mean(axis=0), 1.0, atol=1e-5)
+
