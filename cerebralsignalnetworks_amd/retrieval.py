@@ -62,3 +62,53 @@ def evaluate(FLAGS, gallery_features, query_features, gallery_labels, query_labe
     r = evaluate_full(FLAGS, gallery_features, query_features, gallery_labels, query_labels, dataset)
     print(f"Overall Recall :{r['Recall_Total']} Overall Precision: {r['Precision_Total']}")
     return r["Recall_Total"], r["Precision_Total"]
+
+
+def _all_gather_rows(local, group=None):
+    """Concatenate row blocks of different lengths from all ranks, in rank order (host tensors: the blocks are
+    embeddings / label ids computed once per evaluation, a few MB)."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    local = torch.as_tensor(np.asarray(local)).contiguous()
+    n = torch.tensor([local.shape[0]], dtype=torch.long)
+    sizes = [torch.zeros(1, dtype=torch.long) for _ in range(world)]
+    dist.all_gather(sizes, n, group=group)
+    sizes = [int(v.item()) for v in sizes]
+    pad = torch.zeros((max(sizes),) + tuple(local.shape[1:]), dtype=local.dtype)
+    pad[:local.shape[0]] = local
+    parts = [torch.zeros_like(pad) for _ in range(world)]
+    dist.all_gather(parts, pad, group=group)
+    return torch.cat([p[:k] for p, k in zip(parts, sizes)]).numpy(), sizes
+
+
+def evaluate_distributed(FLAGS, gallery_features, query_features, gallery_labels, query_labels, dataset,
+                         search_fn=None, group=None):
+    """Multi-rank evaluation: every rank holds the embeddings of ITS shard of the gallery
+    and of the queries (the pattern of PerilsEEGDataset.py:191-215, where shards are gathered to rank 0).  The
+    gallery is all-gathered and kept replicated, every rank searches its own queries against it (csn_l2_topk),
+    and the per-query neighbour lists are gathered so that every rank reports the same Recall / Precision / top-1
+    as a single-process ``evaluate_full`` over the concatenated data.  Labels are the reference's label dicts.
+    ``search_fn(gallery, query, k) -> (D, I)`` defaults to the HIP search."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return evaluate_full(FLAGS, gallery_features, query_features, gallery_labels, query_labels, dataset)
+    topK = FLAGS.topK
+    search = search_fn or l2_search
+    by_id = {v["ClassId"]: v for v in list(gallery_labels) + list(query_labels)}
+    gal, _ = _all_gather_rows(np.asarray(gallery_features, dtype=np.float32).reshape(len(gallery_features), -1), group)
+    gal_ids, _ = _all_gather_rows(np.array([l["ClassId"] for l in gallery_labels], dtype=np.int64), group)
+    qry = np.asarray(query_features, dtype=np.float32).reshape(len(query_features), -1)
+    D_loc, I_loc = search(gal, qry, topK) if len(qry) else (np.zeros((0, topK), np.float32), np.zeros((0, topK), np.int64))
+    I_all, _ = _all_gather_rows(np.asarray(I_loc, dtype=np.int64), group)
+    D_all, _ = _all_gather_rows(np.asarray(D_loc, dtype=np.float32), group)
+    q_ids, _ = _all_gather_rows(np.array([l["ClassId"] for l in query_labels], dtype=np.int64), group)
+    # label dicts by class id: every rank needs the dict of every class that occurs anywhere
+    ids_known = sorted(by_id)
+    names = [None] * dist.get_world_size(group)
+    dist.all_gather_object(names, {k: by_id[k] for k in ids_known}, group=group)
+    for d in names:
+        by_id.update(d)
+    recall, precision, scores, top1 = _bookkeeping(I_all, [by_id[int(k)] for k in gal_ids], [by_id[int(k)] for k in q_ids],
+                                                   dataset.class_id_to_str, dataset.class_str_to_id, topK)
+    return dict(Recall_Total=recall, Precision_Total=precision, class_scores=scores, top1=top1, D=D_all, I=I_all)
+

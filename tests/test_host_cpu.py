@@ -150,3 +150,58 @@ def test_classwise_channel_norm_matches_oracle_both_modes():
                 np.testing.assert_allclose(sel.mean(axis=2).mean(axis=0), 0.0, atol=1e-5)
                 np.testing.assert_allclose(sel.std(axis=2).mean(axis=0), 1.0, atol=1e-5)
 
+
+def _eval_data(seed=7, ng=90, nq=33, d=16, ncls=6):
+    rng = np.random.default_rng(seed)
+    cents = rng.standard_normal((ncls, d)) * 2.0
+    gl = rng.integers(0, ncls, ng)
+    ql = rng.integers(0, ncls, nq)
+    gal = (cents[gl] + rng.standard_normal((ng, d))).astype(np.float32)
+    qry = (cents[ql] + rng.standard_normal((nq, d))).astype(np.float32)
+    lab = lambda k: {"ClassId": int(k), "ClassName": f"class_{int(k)}", "imagenetClassId": str(int(k))}
+    return gal, qry, [lab(k) for k in gl], [lab(k) for k in ql], ncls
+
+
+class _DS:
+    def __init__(self, ncls):
+        self.class_id_to_str = {k: f"class_{k}" for k in range(ncls)}
+        self.class_str_to_id = {f"class_{k}": k for k in range(ncls)}
+
+
+def _eval_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    from types import SimpleNamespace
+    from cerebralsignalnetworks_amd import retrieval
+    from oracle import retrieval as oracle_retrieval
+    gal, qry, gl, ql, ncls = _eval_data()
+    gs, qs = slice(rank, None, world), slice(rank * 17, (rank + 1) * 17 if rank + 1 < world else None)   # ragged shards
+    search = lambda g, q, k: oracle_retrieval.l2_topk(g, q, k)                          # the checker stands in for the GPU
+    r = retrieval.evaluate_distributed(SimpleNamespace(topK=5), gal[gs], qry[qs], gl[gs], ql[qs], _DS(ncls),
+                                       search_fn=search)
+    out[rank] = (r["Recall_Total"], r["Precision_Total"], r["top1"], r["I"].shape)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_distributed_retrieval_eval_two_process_gloo():
+    """Sharded gallery + sharded queries give every rank the single-process Recall / Precision / top-1 (the search
+    itself is the HIP kernel in production; here the oracle's brute force stands in, on CPU)."""
+    from oracle import retrieval as oracle_retrieval
+    world, port = 2, 29613
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_eval_worker, args=(world, port, out), nprocs=world, join=True)
+    gal, qry, gl, ql, ncls = _eval_data()
+    # single-process reference over the data in the order the ranks concatenate it
+    g_order = np.concatenate([np.arange(len(gal))[r::world] for r in range(world)])
+    q_order = np.concatenate([np.arange(len(qry))[r * 17:(r + 1) * 17 if r + 1 < world else None] for r in range(world)])
+    ds = _DS(ncls)
+    rec, prec = oracle_retrieval.evaluate(gal[g_order], qry[q_order], [gl[i] for i in g_order], [ql[i] for i in q_order],
+                                          ds.class_id_to_str, topK=5)[:2]
+    for r in range(world):
+        assert abs(out[r][0] - rec) < 1e-9 and abs(out[r][1] - prec) < 1e-9, (out[r], rec, prec)
+        assert out[r][3] == (len(qry), 5)
+    assert out[0] == out[1]
+
