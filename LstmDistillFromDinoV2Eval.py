@@ -32,7 +32,7 @@ def load_checkpoint_into(model, path):
 def main(argv=None):
     from cerebralsignalnetworks_amd import Model, EEGFilters
     from cerebralsignalnetworks_amd.dataset import EEGDataset
-    from cerebralsignalnetworks_amd.retrieval import evaluate_full
+    from cerebralsignalnetworks_amd.retrieval import evaluate_distributed
     from cerebralsignalnetworks_amd.trainer import DistillTrainer
 
     p = build_parser()
@@ -41,7 +41,10 @@ def main(argv=None):
     if not torch.cuda.is_available():
         print('Does not support evaluation without GPU.')
         sys.exit(1)
-    device = torch.device("cuda", 0)
+    # one process per GPU when launched with torchrun: the gallery and the queries are sharded over the ranks
+    import LstmDistillFromDinoV2Train as train_cli
+    rank, world, local = train_cli.init_distributed()
+    device = torch.device("cuda", local)
     os.makedirs(FLAGS.log_dir, exist_ok=True)
     t0 = time.perf_counter()
     if FLAGS.synthetic:
@@ -62,13 +65,15 @@ def main(argv=None):
     N = len(dataset)
     perm = torch.randperm(N, generator=torch.Generator().manual_seed(43))      # Eval.py:325-326
     n_train = int(round(0.8 * N))
-    tr, te = perm[:n_train].to(device), perm[n_train:].to(device)
+    tr, te = perm[:n_train][rank::world].to(device), perm[n_train:][rank::world].to(device)
     gallery = trainer.embed_all(dataset.eeg_all[tr], FLAGS.batch_size).cpu().numpy()
     query = trainer.embed_all(dataset.eeg_all[te], FLAGS.batch_size).cpu().numpy()
     glab = [dataset.getLabelbyIndex(int(i)) for i in tr.cpu()]
     qlab = [dataset.getLabelbyIndex(int(i)) for i in te.cpu()]
-    r = evaluate_full(FLAGS, list(gallery), list(query), glab, qlab, dataset)
+    r = evaluate_distributed(FLAGS, list(gallery), list(query), glab, qlab, dataset)
     dt = time.perf_counter() - t0
+    if rank != 0:
+        return r
     print(f"Overall Recall :{r['Recall_Total']} Overall Precision: {r['Precision_Total']} top1: {r['top1']:.4f}")
     base = f"{FLAGS.log_dir}/Theperils_sub_{FLAGS.query_subject}_Scores"
     out = {"data": r["class_scores"], "metadata": {"processing_time": f"{dt:.2f}s", "flags": vars(FLAGS),

@@ -69,16 +69,18 @@ def _all_gather_rows(local, group=None):
     embeddings / label ids computed once per evaluation, a few MB)."""
     import torch.distributed as dist
     world = dist.get_world_size(group)
-    local = torch.as_tensor(np.asarray(local)).contiguous()
-    n = torch.tensor([local.shape[0]], dtype=torch.long)
-    sizes = [torch.zeros(1, dtype=torch.long) for _ in range(world)]
+    # RCCL moves device tensors only; gloo (CPU tests) host tensors
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    local = torch.as_tensor(np.asarray(local)).contiguous().to(dev)
+    n = torch.tensor([local.shape[0]], dtype=torch.long, device=dev)
+    sizes = [torch.zeros(1, dtype=torch.long, device=dev) for _ in range(world)]
     dist.all_gather(sizes, n, group=group)
     sizes = [int(v.item()) for v in sizes]
-    pad = torch.zeros((max(sizes),) + tuple(local.shape[1:]), dtype=local.dtype)
+    pad = torch.zeros((max(sizes),) + tuple(local.shape[1:]), dtype=local.dtype, device=dev)
     pad[:local.shape[0]] = local
     parts = [torch.zeros_like(pad) for _ in range(world)]
     dist.all_gather(parts, pad, group=group)
-    return torch.cat([p[:k] for p, k in zip(parts, sizes)]).numpy(), sizes
+    return torch.cat([p[:k] for p, k in zip(parts, sizes)]).cpu().numpy(), sizes
 
 
 def evaluate_distributed(FLAGS, gallery_features, query_features, gallery_labels, query_labels, dataset,
