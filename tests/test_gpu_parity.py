@@ -652,3 +652,39 @@ def test_dino_self_distillation_trainer_runs(cuda, tmp_path):
     torch.save({"teacher": ck["teacher"]}, os.path.join(str(tmp_path), "t.pth"))
     res = load_checkpoint_into(m, os.path.join(str(tmp_path), "t.pth"))
     assert not [k for k in res.missing_keys if k.startswith("lstm.")]
+
+
+def test_handoffs_identical_under_uneven_load(cuda):
+    """The in-kernel hand-offs of the weight-stationary kernels (flags + slabs through one XCD's L2) while a second
+    stream streams 256 MB copies through HBM / L2 and takes CUs at random moments: every output and gradient must
+    equal the quiet run bit for bit and no bounded wait may time out (tools/handoff_stress.py is the long form)."""
+    from cerebralsignalnetworks_amd.lstm_model import HipLSTM
+    B, T, C, H, L = 256, 96, 128, 768, 2
+    torch.manual_seed(1)
+    m = HipLSTM(C, H, L, compute_dtype=torch.bfloat16).to(cuda)
+    x = torch.randn(B, T, C, device=cuda)
+    dy = torch.randn(B, H, device=cuda)
+
+    def run():
+        for p in m.parameters():
+            p.grad = None
+        xt = x.clone().requires_grad_(True)
+        y = m(xt)
+        (y * dy).sum().backward()
+        torch.cuda.synchronize()
+        for plan in m.all_plans():
+            assert plan.status() == 0
+        return [y.detach().clone()] + [p.grad.clone() for p in m.parameters()] + [xt.grad.clone()]
+
+    ref = run()
+    side = torch.cuda.Stream()
+    big = [torch.empty(64 << 20, dtype=torch.float32, device=cuda) for _ in range(3)]
+    for rep in range(4):
+        with torch.cuda.stream(side):
+            for k in range(12 + 6 * rep):
+                big[(k + 1) % 3].copy_(big[k % 3])
+        out = run()
+        side.synchronize()
+        for a, b in zip(out, ref):
+            assert torch.equal(a, b), f"repetition {rep}: outputs differ under load"
+
