@@ -53,7 +53,7 @@ class HipLSTM(nn.Module):
     fast path) or torch.float32 (exact-f32 MFMA -- the parity path).
     """
 
-    MAX_IDLE_PLANS = 4      # workspaces are large (8 GB at cfg2): keep only a few idle ones
+    MAX_IDLE_PLANS = 4      # workspaces are large (10 GB at cfg2): keep only a few idle ones
 
     def __init__(self, input_size, hidden_size, num_layers=1, compute_dtype=torch.bfloat16):
         super().__init__()
