@@ -670,7 +670,7 @@ __device__ __forceinline__ bf16x8 tr_read_pair(unsigned addr) {
   return u.b;
 }
 
-template <int NSTAGE>
+template <int NSTAGE, bool COLSUM>
 __global__ void __launch_bounds__(512)
 gemm_tn_256_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ Bm, float* __restrict__ slabs,
                    int64_t M, int64_t N, int64_t K, int64_t k_per_split, float* __restrict__ colsum) {
@@ -718,7 +718,8 @@ gemm_tn_256_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ Bm, 
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   // optional column sums of A (the bias gradient: sum over the contraction rows of dgates): the waves that hold
   // the first 64 output columns of the first column tile multiply their A fragments by a fragment of ones too
-  const bool do_colsum = colsum != nullptr && n0 == 0 && wn == 0;
+  // (a template switch: the extra accumulators cost the plain kernel 8 % even when unused)
+  const bool do_colsum = COLSUM && colsum != nullptr && n0 == 0 && wn == 0;
   const bf16x8 ones = {(bf16_t)1.0f, (bf16_t)1.0f, (bf16_t)1.0f, (bf16_t)1.0f, (bf16_t)1.0f, (bf16_t)1.0f, (bf16_t)1.0f, (bf16_t)1.0f};
   f32x4 acc_cs[8];
 #pragma unroll
@@ -770,12 +771,13 @@ gemm_tn_256_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ Bm, 
 #pragma unroll
       for (int j = 0; j < 4; ++j)
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
-      if (do_colsum) acc_cs[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[i], acc_cs[i], 0, 0, 0);
+      if constexpr (COLSUM)
+        if (do_colsum) acc_cs[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[i], acc_cs[i], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
   }
 
-  if (do_colsum && (lane >> 4) == 0) {       // D[n][m]: every row n holds the same sum; lanes 0..15 write column m
+  if (COLSUM && do_colsum && (lane >> 4) == 0) {       // D[n][m]: every row n holds the same sum; lanes 0..15 write column m
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int64_t m = m0 + wm * 128 + i * 16 + (lane & 15);
@@ -942,17 +944,21 @@ int launch_gemm_tn_slabs(const void* A, const void* B, float* slabs, int64_t M, 
     *S_out = S2;
     static bool attr_done = false;
     if (!attr_done) {
-      if (int rc = ensure_dyn_lds(&gemm_tn_256_kernel<5>, 5 * 32768)) return rc;
-      if (int rc = ensure_dyn_lds(&gemm_tn_256_kernel<4>, 4 * 32768)) return rc;
-      if (int rc = ensure_dyn_lds(&gemm_tn_256_kernel<3>, 3 * 32768)) return rc;
+      if (int rc = ensure_dyn_lds(&gemm_tn_256_kernel<5, false>, 5 * 32768)) return rc;
+      if (int rc = ensure_dyn_lds(&gemm_tn_256_kernel<4, false>, 4 * 32768)) return rc;
+      if (int rc = ensure_dyn_lds(&gemm_tn_256_kernel<3, false>, 3 * 32768)) return rc;
+      if (int rc = ensure_dyn_lds(&gemm_tn_256_kernel<4, true>, 4 * 32768)) return rc;
       attr_done = true;
     }
     dim3 grid((unsigned)(((N + 255) / 256) * ((M + 255) / 256) * S2));
     const char* ns = getenv("CSN_TN_STAGES");
     const int nst = ns ? atoi(ns) : 4;
-    if (nst == 3) gemm_tn_256_kernel<3><<<grid, 512, 3 * 32768, st>>>((const bf16_t*)A, (const bf16_t*)B, slabs, M, N, K, kper2, colsum);
-    else if (nst == 4) gemm_tn_256_kernel<4><<<grid, 512, 4 * 32768, st>>>((const bf16_t*)A, (const bf16_t*)B, slabs, M, N, K, kper2, colsum);
-    else gemm_tn_256_kernel<5><<<grid, 512, 5 * 32768, st>>>((const bf16_t*)A, (const bf16_t*)B, slabs, M, N, K, kper2, colsum);
+    const bf16_t* Ab = (const bf16_t*)A;
+    const bf16_t* Bb = (const bf16_t*)B;
+    if (colsum) gemm_tn_256_kernel<4, true><<<grid, 512, 4 * 32768, st>>>(Ab, Bb, slabs, M, N, K, kper2, colsum);
+    else if (nst == 3) gemm_tn_256_kernel<3, false><<<grid, 512, 3 * 32768, st>>>(Ab, Bb, slabs, M, N, K, kper2, nullptr);
+    else if (nst == 5) gemm_tn_256_kernel<5, false><<<grid, 512, 5 * 32768, st>>>(Ab, Bb, slabs, M, N, K, kper2, nullptr);
+    else gemm_tn_256_kernel<4, false><<<grid, 512, 4 * 32768, st>>>(Ab, Bb, slabs, M, N, K, kper2, nullptr);
     if (colsum && colsum_done) *colsum_done = 1;
     CSN_LAUNCH_CHECK();
     return CSN_OK;
