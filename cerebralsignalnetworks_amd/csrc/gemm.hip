@@ -716,14 +716,17 @@ gemm_tn_256_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ Bm, 
   for (int i = 0; i < 8; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  // optional column sums of A (the bias gradient: sum over the contraction rows of dgates): the waves that hold
-  // the first 64 output columns of the first column tile multiply their A fragments by a fragment of ones too
+  // optional column sums of A (the bias gradient: sum over the contraction rows of dgates): in the workgroups of
+  // the first column tile every wave multiplies two of its eight A fragments by a fragment of ones too (the four
+  // waves that share the A rows split the eight fragments: + 6 % MFMAs there, nothing elsewhere)
   // (a template switch: the extra accumulators cost the plain kernel 8 % even when unused)
-  const bool do_colsum = COLSUM && colsum != nullptr && n0 == 0 && wn == 0;
+  // (the wave index goes through readfirstlane so that the condition around the extra MFMA is a SCALAR branch:
+  // under a mere EXEC mask the MFMA would still execute -- MFMA ignores EXEC -- and add foreign fragments)
+  const int wn_s = __builtin_amdgcn_readfirstlane(wn);
+  const bool do_colsum = COLSUM && colsum != nullptr && n0 == 0;
   const bf16x8 ones = {(bf16_t)1.0f, (bf16_t)1.0f, (bf16_t)1.0f, (bf16_t)1.0f, (bf16_t)1.0f, (bf16_t)1.0f, (bf16_t)1.0f, (bf16_t)1.0f};
-  f32x4 acc_cs[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) acc_cs[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  f32x4 acc_cs[2];
+  acc_cs[0] = acc_cs[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   // byte address (inside a stage) of this lane's first ds_read_b64_tr_b16 of every fragment; the second one
   // (k-rows + 4) is 2048 bytes further
@@ -772,16 +775,16 @@ gemm_tn_256_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ Bm, 
       for (int j = 0; j < 4; ++j)
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
       if constexpr (COLSUM)
-        if (do_colsum) acc_cs[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[i], acc_cs[i], 0, 0, 0);
+        if (do_colsum && (i >> 1) == wn_s) acc_cs[i & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[i], acc_cs[i & 1], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
   }
 
   if (COLSUM && do_colsum && (lane >> 4) == 0) {       // D[n][m]: every row n holds the same sum; lanes 0..15 write column m
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int64_t m = m0 + wm * 128 + i * 16 + (lane & 15);
-      if (m < M) colsum[(int64_t)zsplit * M + m] = acc_cs[i][0];
+    for (int e = 0; e < 2; ++e) {
+      const int64_t m = m0 + wm * 128 + (2 * wn + e) * 16 + (lane & 15);
+      if (m < M) colsum[(int64_t)zsplit * M + m] = acc_cs[e][0];
     }
   }
 

@@ -143,7 +143,9 @@ __global__ void __launch_bounds__(256) lstm_fwd_persist_kernel(PersistFwdArgs a)
   const bf16_t* const x_blk = S.x_blk;
   const bool fused = x_blk != nullptr;
   const int xkb = S.I >> 5;
-  const bool xwave = fused && wave < xkb;
+  // (wave index through readfirstlane: the condition around the x MFMAs must be a SCALAR branch -- MFMA ignores
+  // EXEC, so under a mere EXEC mask it would execute in every wave)
+  const bool xwave = fused && __builtin_amdgcn_readfirstlane(wave) < xkb;
 
   // ---- is this group on one XCD?  Every workgroup adds (1, 1 << its XCC field) to the group's word and
   // waits for all `nslices` arrivals; all of them then see the same word and take the same decision.
