@@ -93,7 +93,7 @@ def test_mfma_layout_identity_times_asymmetric(cuda):
 
 
 @pytest.mark.parametrize("M,N,K", [(256, 384, 128), (300, 260, 72), (128, 128, 64), (64, 3072, 768), (70, 52, 40),
-                                   (1024, 3072, 768), (520, 1028, 320),     # 256 x 128 LDS-DMA ring kernel
+                                   (1024, 3072, 768), (520, 1028, 320), (520, 1536, 320),    # 256 x 128 LDS-DMA ring kernel
                                    (512, 768, 3072)])                       # 128 x 128 LDS-DMA kernel
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
 def test_gemm_nt(cuda, M, N, K, dt):
