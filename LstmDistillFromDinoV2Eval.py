@@ -33,7 +33,7 @@ def main(argv=None):
     from cerebralsignalnetworks_amd import Model, EEGFilters
     from cerebralsignalnetworks_amd.dataset import EEGDataset
     from cerebralsignalnetworks_amd.retrieval import evaluate_distributed
-    from cerebralsignalnetworks_amd.trainer import DistillTrainer
+    from cerebralsignalnetworks_amd.trainer import DistillTrainer, split_indices
 
     p = build_parser()
     p.add_argument('--dino_base_model_weights', type=str, default="")
@@ -63,9 +63,7 @@ def main(argv=None):
     sos = EEGFilters(FLAGS.fs, order=FLAGS.filter_order).sos if FLAGS.filter_order else None
     trainer = DistillTrainer(model, sos, loss="cosine")
     N = len(dataset)
-    perm = torch.randperm(N, generator=torch.Generator().manual_seed(43))      # Eval.py:325-326
-    n_train = int(round(0.8 * N))
-    tr, te = perm[:n_train][rank::world].to(device), perm[n_train:][rank::world].to(device)
+    tr, te = (ix[rank::world].to(device) for ix in split_indices(N, (0.8, 0.2), seed=43))      # random_split, Eval.py:324-325
     gallery = trainer.embed_all(dataset.eeg_all[tr], FLAGS.batch_size).cpu().numpy()
     query = trainer.embed_all(dataset.eeg_all[te], FLAGS.batch_size).cpu().numpy()
     glab = [dataset.getLabelbyIndex(int(i)) for i in tr.cpu()]

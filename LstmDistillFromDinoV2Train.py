@@ -93,7 +93,7 @@ def main(argv=None):
     from cerebralsignalnetworks_amd import Model, EEGFilters
     from cerebralsignalnetworks_amd.dataset import EEGDataset
     from cerebralsignalnetworks_amd.retrieval import evaluate_full
-    from cerebralsignalnetworks_amd.trainer import DistillTrainer, shard_indices
+    from cerebralsignalnetworks_amd.trainer import DistillTrainer, shard_indices, split_indices
     from cerebralsignalnetworks_amd.losses import HyperParams
 
     FLAGS, _unparsed = build_parser().parse_known_args(argv)
@@ -123,9 +123,7 @@ def main(argv=None):
     features_length = dataset.features_all.shape[1]
     C = dataset.eeg_all.shape[1]
 
-    perm = torch.randperm(N, generator=torch.Generator().manual_seed(43))      # random_split([0.8,0.2], seed 43), :289
-    n_train = int(round(0.8 * N))
-    train_idx, val_idx = perm[:n_train].to(device), perm[n_train:].to(device)
+    train_idx, val_idx = (ix.to(device) for ix in split_indices(N, (0.8, 0.2), seed=43))      # random_split, :289-290
 
     dtype = torch.bfloat16 if FLAGS.dtype == "bf16" else torch.float32
     include_top = FLAGS.loss == "featdist"

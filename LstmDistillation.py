@@ -66,7 +66,7 @@ def main(argv=None):
     from cerebralsignalnetworks_amd.dataset import EEGDataset
     from cerebralsignalnetworks_amd.dino import (DINOHead, DINOLoss, MultiCropWrapper, cosine_scheduler, ema_update,
                                                  temporal_crops)
-    from cerebralsignalnetworks_amd.trainer import FlatGrads, shard_indices
+    from cerebralsignalnetworks_amd.trainer import FlatGrads, shard_indices, split_indices
 
     FLAGS, _ = build_parser().parse_known_args(argv)
     rank, world, local = init_distributed()
@@ -81,8 +81,7 @@ def main(argv=None):
         dataset = EEGDataset(eeg_signals_path=FLAGS.eeg_dataset, imagesRoot=FLAGS.images_root,
                              time_low=FLAGS.time_low, time_high=FLAGS.time_high, device=device)
     N, C = len(dataset), dataset.eeg_all.shape[1]
-    perm = torch.randperm(N, generator=torch.Generator().manual_seed(43))
-    train_idx = perm[: int(round(0.8 * N))].to(device)
+    train_idx = split_indices(N, (0.8, 0.2), seed=43)[0].to(device)      # random_split([0.8, 0.2], seed 43)
 
     dtype = torch.bfloat16 if FLAGS.dtype == "bf16" else torch.float32
     def make():

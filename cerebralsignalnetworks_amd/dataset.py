@@ -35,8 +35,9 @@ class EEGDataset(Dataset):
                  imagesRoot="./data/images/imageNet_images", apply_norm_with_stds_and_means=False,
                  apply_channel_wise_norm=False, preprocessin_fn=None, inference_mode=True, onehotencode_label=False,
                  synthetic=0, synthetic_channels=128, synthetic_samples=500, n_classes=40, feature_dim=384, seed=43,
-                 device=None, compat_label_bug=False, **_ignored):
+                 device=None, compat_label_bug=False, compat_stale_index=False, flavour="perils", **_ignored):
         assert subset in ('train', 'val', 'test')
+        assert flavour in ("perils", "spampinato")       # utils/PerilsEEGDataset.py vs utils/EEGDataset.py
         self.time_low, self.time_high = time_low, time_high
         self.imagesRoot, self.preprocessin_fn = imagesRoot, preprocessin_fn
         self.inference_mode, self.onehotencode_label = inference_mode, onehotencode_label
@@ -60,17 +61,21 @@ class EEGDataset(Dataset):
             feats = torch.randn(synthetic, feature_dim, generator=torch.Generator().manual_seed(seed + 1))
             self.features_all = feats.to(self.device)
             self.image_features_extracted = True
-            self.mean, self.std = raw.mean(), raw.std()
+            self.mean = torch.stack([r.mean() for r in raw]).mean()
+            self.std = torch.stack([r.std() for r in raw]).mean()
         else:
             loaded = torch.load(eeg_signals_path, weights_only=True)       # ConvertToPth.py:170-201 format
             items = loaded["dataset"]
-            if eeg_splits_path:                                             # EEGDataset.py:52-69
+            if flavour == "spampinato":
+                # utils/EEGDataset.py:52-53,99-128: split file -> subset indexes; subject != 0 keeps that subject,
+                # subject == 0 keeps every subject not in exclude_subjects; per-channel (eeg - means) / stddevs
                 splits = torch.load(eeg_splits_path, weights_only=True)
-                keep = [i for i in splits["splits"][0][subset] if i < len(items)]
+                keep = [int(i) for i in splits["splits"][0][subset]]
+                if subject != 0:
+                    keep = [i for i in keep if int(items[i]["subject"]) == subject]
+                else:
+                    keep = [i for i in keep if int(items[i]["subject"]) not in exclude_subjects]
                 items = [items[i] for i in keep]
-            if subject and any("subject" in it for it in items) and eeg_splits_path:
-                items = [it for it in items if it.get("subject", subject) == subject
-                         and it.get("subject") not in exclude_subjects]
             raw = torch.stack([it["eeg"].float() for it in items])         # [N,C,T_raw]
             self.labels = torch.tensor([int(it["label"]) for it in items])
             self.subjects = torch.tensor([int(it.get("subject", 0)) for it in items])
@@ -78,17 +83,30 @@ class EEGDataset(Dataset):
             image_names = loaded["images"]
             self.images = [image_names[int(it["image"])] for it in items]
             self._read_label_file(set(n.split("_")[0] for n in image_names))
-            if apply_norm_with_stds_and_means and "means" in loaded and "stddevs" in loaded:
-                raw = (raw - torch.as_tensor(loaded["means"]).reshape(1, -1, 1).float()) \
-                    / torch.as_tensor(loaded["stddevs"]).reshape(1, -1, 1).float()      # EEGDataset.py:104-105
-            self.mean = torch.stack([r.mean() for r in raw]).mean()        # PerilsEEGDataset.py:90-103
-            self.std = torch.stack([r.std() for r in raw]).mean()
+            if flavour == "spampinato":
+                if apply_norm_with_stds_and_means:                          # EEGDataset.py:104-105 (at load)
+                    means, stds = loaded["means"], loaded["stddevs"]
+                    means = means[0] if isinstance(means, (list, tuple)) else means
+                    stds = stds[0] if isinstance(stds, (list, tuple)) else stds
+                    raw = (raw - torch.as_tensor(means).reshape(1, -1, 1).float()) \
+                        / torch.as_tensor(stds).reshape(1, -1, 1).float()
+            else:
+                # PerilsEEGDataset.py:90-103: scalars = mean over records of the record mean / std (torch std, ddof 1),
+                # taken in the stored dtype; applied per item in __getitem__ (:572-573)
+                self.mean = torch.stack([it["eeg"].mean() for it in items]).mean().float()
+                self.std = torch.stack([it["eeg"].std() for it in items]).mean().float()
             self.features_all = None
-        if len(filter_channels) > 0:
-            raw = raw[:, list(filter_channels), :]
+        self.flavour = flavour
+        self.filter_channels = list(filter_channels)
+        self.apply_channel_wise_norm = apply_channel_wise_norm
+        if len(self.filter_channels) > 0:
+            raw = raw[:, self.filter_channels, :]
         self.eeg_all = raw[:, :, time_low:time_high].contiguous().to(self.device)      # [N,C,T]
         self.labels_dev = self.labels.to(self.device)
         self.size = self.eeg_all.shape[0]
+        if apply_channel_wise_norm and flavour == "perils" and not synthetic:
+            self.transformEEGDataToChannelWiseNorm(compat_stale_index=compat_stale_index,      # :132-134
+                                                   stored_float32=items[0]["eeg"].dtype == torch.float32)
 
     def _read_label_file(self, wanted):
         path = f"{self.imagesRoot}/labels.txt"                              # PerilsEEGDataset.py:76-88
@@ -117,8 +135,15 @@ class EEGDataset(Dataset):
     def __getitem__(self, i):
         i = int(i)
         eeg = self.eeg_all[i].t()                                          # [T,C]
-        if self.apply_norm_with_stds_and_means and not hasattr(self, "class_labels"):
-            eeg = (eeg - self.mean) / self.std
+        if len(self.filter_channels) > 0:
+            # :552-565: the selected columns, each optionally z-scored (numpy std, ddof 0), and -- as the reference's
+            # final ``.t()`` leaves it -- channel-first [len(filter_channels), T]
+            # (eeg_all already holds only the selected channels)
+            if self.apply_channel_wise_norm:
+                eeg = (eeg - eeg.mean(dim=0, keepdim=True)) / eeg.std(dim=0, unbiased=False, keepdim=True)
+            eeg = eeg.t()
+        if self.apply_norm_with_stds_and_means and self.flavour == "perils":
+            eeg = (eeg - self.mean) / self.std                             # :572-573, scalars
         label = self.getLabelbyIndex(i)
         if not self.inference_mode:
             label = label["ClassId"]
@@ -172,14 +197,17 @@ class EEGDataset(Dataset):
         self.image_features_extracted = True
 
     @torch.no_grad()
-    def transformEEGDataToChannelWiseNorm(self, compat_stale_index=False):
+    def transformEEGDataToChannelWiseNorm(self, compat_stale_index=False, stored_float32=False):
         """Class-wise, channel-wise normalisation of the resident segments (PerilsEEGDataset.py:464-507): per class
         and channel, (x - mean of the per-segment means) / (mean of the per-segment stds, ddof 0), statistics over
         the [time_low:time_high] window.  One pass on the device instead of the reference's N x C Python loop.
 
-        compat_stale_index=True reproduces what the reference's code actually leaves behind (it stores every
-        result into the LAST record -- ``self.subsetData[i]`` with a stale ``i``, :507 -- and indexes the
-        channel-first record as ``eeg[:, ch]``, :503-506): only record N-1 changes."""
+        compat_stale_index=True reproduces what the reference's code actually leaves behind: it indexes the
+        channel-first record as ``eeg[:, ch]`` (:503-506: channel ch's statistics land on raw time sample ch), stores
+        every result into entry N-1 (``self.subsetData[i]`` with a stale ``i``, :507) and, depending on the stored
+        dtype, works on a copy (float64 records, what ConvertToPth.py writes) or in place (``stored_float32``:
+        ``.float().cpu().numpy()`` aliases a float32 record).  The host walks the visiting order once to find which
+        class statistics end up applied to which record; the arithmetic runs on the device."""
         x = self.eeg_all                                                # [N, C, T]
         N, C, T = x.shape
         labels = self.labels_dev.long()
@@ -192,19 +220,41 @@ class EEGDataset(Dataset):
         if not compat_stale_index:
             self.eeg_all = ((x - cls_mean[labels][:, :, None]) / cls_std[labels][:, :, None]).contiguous()
             return
-        seen = []
-        for k in self.labels.tolist():                                   # classes in order of first appearance
-            if k not in seen:
-                seen.append(k)
-        last_class = seen[-1]
-        last_idx = int((self.labels == last_class).nonzero()[-1])
-        rec = x[last_idx].clone()
-        lo = max(0, self.time_low)
+        # which (source record, class statistics in order) does every entry end up holding?
+        lab = self.labels.tolist()
+        order = list(dict.fromkeys(lab))
+        applied = [[] for _ in range(N)]         # per physical array: classes applied, in order
+        source = list(range(N))                  # per physical array: the original record it started from
+        aliased = [bool(stored_float32)] * N
+        slot = list(range(N))
+        for k in order:
+            for i in (j for j in range(N) if lab[j] == k):
+                phys = slot[i]
+                if not aliased[phys]:
+                    applied.append(list(applied[phys]))
+                    source.append(source[phys])
+                    aliased.append(True)
+                    phys = len(applied) - 1
+                applied[phys].append(k)
+                slot[N - 1] = phys
         chs = torch.arange(C, device=x.device)
-        cols = chs - lo
+        cols = chs - max(0, self.time_low)
         ok = (cols >= 0) & (cols < T)
-        rec[:, cols[ok]] = (rec[:, cols[ok]] - cls_mean[last_class][chs[ok]][None, :]) / cls_std[last_class][chs[ok]][None, :]
-        self.eeg_all[N - 1] = rec
+        cols, chs = cols[ok], chs[ok]
+        out = x.clone()
+        simple = [i for i in range(N) if slot[i] == i and applied[i] == [lab[i]]]
+        if simple:                                # the common case of the in-place form: own class, once
+            si = torch.tensor(simple, device=x.device)
+            m, sd = cls_mean[labels[si]][:, chs], cls_std[labels[si]][:, chs]
+            out[si[:, None], :, cols[None, :]] = ((x[si][:, :, cols] - m[:, None, :]) / sd[:, None, :]).permute(0, 2, 1)
+        for i in range(N):
+            if i in simple or (slot[i] == i and not applied[i]):
+                continue
+            rec = x[source[slot[i]]].clone()
+            for k in applied[slot[i]]:
+                rec[:, cols] = (rec[:, cols] - cls_mean[k][chs][None, :]) / cls_std[k][chs][None, :]
+            out[i] = rec
+        self.eeg_all = out
 
     @torch.no_grad()
     def transformEEGDataLSTMByList(self, model, data_loader):

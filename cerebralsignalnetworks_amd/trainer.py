@@ -52,6 +52,17 @@ class FlatGrads:
             self.flat.div_(world)
 
 
+def split_indices(n, fractions=(0.8, 0.2), seed=43):
+    """The reference's train / validation split: ``torch.utils.data.random_split(dataset, [0.8, 0.2],
+    generator=torch.Generator().manual_seed(43))`` (LstmDistillFromDinoV2Train.py:289-290, ...Eval.py:324-325).
+    Its semantics (floor of each fraction, the remainder dealt round-robin from the first split, consecutive
+    slices of one ``randperm``) are taken from ``random_split`` itself, applied to ``range(n)``.
+    Returns one int64 index tensor per fraction."""
+    from torch.utils.data import random_split
+    parts = random_split(range(n), list(fractions), generator=torch.Generator().manual_seed(seed))
+    return [torch.as_tensor(list(part.indices), dtype=torch.long) for part in parts]
+
+
 def shard_indices(n, epoch, seed, rank, world, shuffle=True, device="cpu"):
     """DistributedSampler semantics: pad to a multiple of world, rank takes r::world."""
     if shuffle:

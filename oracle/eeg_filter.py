@@ -66,6 +66,33 @@ def zscore_rows(y, ddof=0):
     return (y - mean) / std
 
 
+def dataset_item(raw_ct, time_low, time_high, filter_channels=(), channel_wise_norm=False, mean=None, std=None,
+                 means_c=None, stds_c=None):
+    """The EEG part of ``EEGDataset.__getitem__`` (utils/PerilsEEGDataset.py:541-573; utils/EEGDataset.py:539-567):
+    stored [C, T_raw] -> ``.float().t()`` -> window [time_low:time_high].  With ``filter_channels``: those columns
+    only, each optionally z-scored by ``normlizeEEG`` on a numpy array (ddof 0), and the result transposed BACK to
+    channel-first [len(filter_channels), T] (:565 ``.t()``).  ``mean``/``std``: Perils scalar dataset-level
+    normalisation (:572-573).  ``means_c``/``stds_c`` [C,1]: the Spampinato per-channel form, applied to the
+    channel-first record before the transpose (utils/EEGDataset.py:543-544)."""
+    rec = np.asarray(raw_ct, np.float32)
+    if means_c is not None:
+        rec = (rec - np.asarray(means_c, np.float32)) / np.asarray(stds_c, np.float32)
+    eeg = rec.T
+    if len(filter_channels) > 0:
+        out = np.zeros((time_high - time_low, len(filter_channels)), np.float32)
+        for j, ch in enumerate(filter_channels):
+            out[:, j] = eeg[time_low:time_high, ch]
+            if channel_wise_norm:
+                col = out[:, j]
+                out[:, j] = (col - col.mean()) / col.std()
+        eeg = out.T
+    else:
+        eeg = eeg[time_low:time_high, :]
+    if mean is not None:
+        eeg = (eeg - np.float32(mean)) / np.float32(std)
+    return eeg
+
+
 def eeg_bandpass_znorm(x_bct, sos, ddof=0, time_major=False):
     """x[B,C,T] -> filtered + z-scored, laid out for the LSTM.
 
@@ -151,7 +178,7 @@ def synthetic_eeg(n, channels=128, samples=500, fs=1000.0, freq=40.0, amp=0.5, s
     return x.astype(np.float32)
 
 
-def classwise_channel_norm(eeg_nct, class_ids, time_low=0, compat_stale_index=False):
+def classwise_channel_norm(eeg_nct, class_ids, time_low=0, compat_stale_index=False, stored_float32=False):
     """Class-wise, channel-wise normalisation of a dataset, restating
     /root/reference/utils/PerilsEEGDataset.py:464-507 (``transformEEGDataToChannelWiseNorm``).
 
@@ -162,11 +189,14 @@ def classwise_channel_norm(eeg_nct, class_ids, time_low=0, compat_stale_index=Fa
 
     compat_stale_index=False: what the function is written to do -- every segment of the class normalised with
     its class's per-channel statistics.
-    compat_stale_index=True: what the reference's code does -- (a) ``:507`` stores into ``self.subsetData[i]`` with
-    ``i`` left over from the first loop (= N-1), so only the LAST record is ever overwritten, each time with the
-    transformed copy of the record being visited; (b) the record is stored channel-first ``[C, T_raw]`` but
+    compat_stale_index=True: what the reference's code leaves behind (pinned by executing it,
+    tests/golden/ref_preproc.npz).  Three things combine: (a) the record is stored channel-first ``[C, T_raw]`` but
     ``:503-506`` index it as ``eeg[:, ch]``, so "channel" ch's statistics are applied to the raw TIME sample ch of
-    every channel.  The final state is: record N-1 = that transform of the last record of the last class.
+    every channel; (b) ``:507`` stores into ``self.subsetData[i]`` with ``i`` left over from the first loop (= N-1),
+    so entry N-1 is re-pointed at the transformed array of every record visited; (c) ``.float().cpu().numpy()``
+    (:499-500) copies a float64 record but ALIASES a float32 one -- with float32 storage (``stored_float32``) every
+    visited record is therefore also changed in place, and with float64 storage only the arrays the function
+    itself created (float32) are: entry N-1, when visited after it has been re-pointed, transforms that array again.
     """
     x = np.array(eeg_nct, dtype=np.float32, copy=True)
     N, C, T = x.shape
@@ -174,25 +204,39 @@ def classwise_channel_norm(eeg_nct, class_ids, time_low=0, compat_stale_index=Fa
     for k in class_ids:
         if int(k) not in order:
             order.append(int(k))
-    out = x.copy()
+    stats = {}
     for k in order:
         idx = [i for i in range(N) if int(class_ids[i]) == k]
         means = np.array([[x[i, c].mean() for c in range(C)] for i in idx], dtype=np.float32)
         stds = np.array([[x[i, c].std() for c in range(C)] for i in idx], dtype=np.float32)
-        mean_mean, mean_std = means.mean(axis=0), stds.mean(axis=0)
-        for i in idx:
-            if not compat_stale_index:
-                out[i] = (x[i] - mean_mean[:, None]) / mean_std[:, None]
-            else:
-                rec = x[i].copy()                       # [C, T] = raw columns time_low .. time_low + T - 1
-                for ch in range(C):
-                    col = ch - time_low
-                    if 0 <= col < T:
-                        rec[:, col] = (rec[:, col] - mean_mean[ch]) / mean_std[ch]
-                out[N - 1] = rec
-    if compat_stale_index:
-        keep = out[N - 1].copy()
+        stats[k] = (idx, means.mean(axis=0), stds.mean(axis=0))
+    if not compat_stale_index:
         out = x.copy()
-        out[N - 1] = keep
-    return out
+        for k in order:
+            idx, mm, ms = stats[k]
+            for i in idx:
+                out[i] = (x[i] - mm[:, None]) / ms[:, None]
+        return out
 
+    def transform(rec, k):                       # in place, raw columns ch = 0..C-1 of the channel-first record
+        _, mm, ms = stats[k]
+        for ch in range(C):
+            col = ch - time_low
+            if 0 <= col < T:
+                rec[:, col] = (rec[:, col] - mm[ch]) / ms[ch]
+
+    recs = [x[i].copy() for i in range(N)]       # physical arrays; entries point at them
+    aliased = [bool(stored_float32)] * N         # does .float().cpu().numpy() alias this array?
+    slot = list(range(N))
+    for k in order:
+        for i in stats[k][0]:
+            phys = slot[i]
+            if aliased[phys]:
+                transform(recs[phys], k)
+            else:
+                recs.append(recs[phys].copy())
+                aliased.append(True)             # created by torch.from_numpy(float32 array)
+                phys = len(recs) - 1
+                transform(recs[phys], k)
+            slot[N - 1] = phys
+    return np.stack([recs[slot[i]] for i in range(N)])

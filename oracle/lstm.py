@@ -142,6 +142,51 @@ def model_backward(dfeat, params, saved, num_layers, dcls=None, dtype=np.float64
     return dx, grads
 
 
+def reference_lstm_model(x_b_ts_ch, params, num_layers, target=None, dtype=np.float64):
+    """``LSTMModel`` of LSTMDistillRetreival.py:85-110: the input [B, timespan, channels] is *viewed* (memory
+    reinterpreted, not transposed) as [B, channels, timespan] (:97-98), i.e. the recurrence runs over ``channels``
+    steps with ``timespan`` features; zero initial state; fc on the last step.  With ``target``: also the
+    CosineSimilarityLoss (LstmDistillFromDinoV2Train.py:36-43) and every parameter gradient.
+    """
+    from . import losses
+    x = np.ascontiguousarray(np.asarray(x_b_ts_ch))
+    B, TS, CH = x.shape
+    seq = x.reshape(B, CH, TS)
+    feat, saved = model_forward(seq, params, num_layers, dtype=dtype, return_saved=True)
+    if target is None:
+        return feat
+    loss = losses.cosine_similarity_loss(feat, target)
+    _, grads = model_backward(losses.cosine_similarity_loss_grad(feat, target), params, saved, num_layers, dtype=dtype)
+    return feat, loss, grads
+
+
+def reference_lstm_model_all_steps(x_b_ts_ch, params, num_layers, dfeat=None, dcls=None, dtype=np.float64):
+    """``LSTMModel`` of LSTMDistill.py:112-142: same view, then fc on EVERY step, class_pred on the un-rectified
+    fc output, ReLU on the returned features (:137-141).  With (dfeat, dcls) = dLoss/d(returned feat, cls):
+    the parameter gradients.
+    """
+    x = np.ascontiguousarray(np.asarray(x_b_ts_ch))
+    B, TS, CH = x.shape
+    seq = x.reshape(B, CH, TS)
+    lstm_p = {k[len("lstm."):]: v for k, v in params.items() if k.startswith("lstm.")}
+    y, saved = lstm_forward(seq, lstm_p, num_layers, dtype, return_saved=True)            # [B, CH, H]
+    wf, bf = np.asarray(params["fc.weight"], dtype), np.asarray(params["fc.bias"], dtype)
+    wc, bc = np.asarray(params["class_pred.weight"], dtype), np.asarray(params["class_pred.bias"], dtype)
+    pre = y @ wf.T + bf
+    cls = pre @ wc.T + bc
+    feat = np.maximum(pre, 0.0)
+    if dfeat is None:
+        return feat, cls
+    dpre = np.asarray(dfeat, dtype) * (pre > 0) + np.asarray(dcls, dtype) @ wc
+    grads = {"class_pred.weight": np.einsum("btn,btd->nd", np.asarray(dcls, dtype), pre),
+             "class_pred.bias": np.asarray(dcls, dtype).sum(axis=(0, 1)),
+             "fc.weight": np.einsum("btd,bth->dh", dpre, y), "fc.bias": dpre.sum(axis=(0, 1))}
+    _, g = lstm_backward(dpre @ wf, lstm_p, saved, num_layers, dtype)
+    for k, v in g.items():
+        grads["lstm." + k] = v
+    return feat, cls, grads
+
+
 def init_params(input_size, hidden, num_layers, out_features, n_classes=None, seed=43, dtype=np.float32):
     """Deterministic numpy init with nn.LSTM / nn.Linear's U(-1/sqrt(fan), 1/sqrt(fan)) ranges."""
     rng = np.random.default_rng(seed)
