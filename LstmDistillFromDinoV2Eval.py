@@ -66,6 +66,7 @@ def main(argv=None):
     tr, te = (ix[rank::world].to(device) for ix in split_indices(N, (0.8, 0.2), seed=43))      # random_split, Eval.py:324-325
     gallery = trainer.embed_all(dataset.eeg_all[tr], FLAGS.batch_size).cpu().numpy()
     query = trainer.embed_all(dataset.eeg_all[te], FLAGS.batch_size).cpu().numpy()
+    trainer.check_device_status()      # every embedding batch above: a timed-out in-kernel hand-off invalidates the run
     glab = [dataset.getLabelbyIndex(int(i)) for i in tr.cpu()]
     qlab = [dataset.getLabelbyIndex(int(i)) for i in te.cpu()]
     r = evaluate_distributed(FLAGS, list(gallery), list(query), glab, qlab, dataset)

@@ -66,7 +66,7 @@ def main(argv=None):
     from cerebralsignalnetworks_amd.dataset import EEGDataset
     from cerebralsignalnetworks_amd.dino import (DINOHead, DINOLoss, MultiCropWrapper, cosine_scheduler, ema_update,
                                                  temporal_crops)
-    from cerebralsignalnetworks_amd.trainer import FlatGrads, shard_indices, split_indices
+    from cerebralsignalnetworks_amd.trainer import FlatGrads, check_device_status, shard_indices, split_indices
 
     FLAGS, _ = build_parser().parse_known_args(argv)
     rank, world, local = init_distributed()
@@ -145,6 +145,8 @@ def main(argv=None):
             ema_update(student, teacher, momentum_schedule[it])
             losses.append(loss.detach())
         epoch_loss = float(torch.stack(losses).mean().item())
+        check_device_status(student)       # per epoch (sticky word): student and teacher share no plans
+        check_device_status(teacher)
         history.append(epoch_loss)
         if rank == 0:
             save_dict = {'student': student.state_dict(), 'teacher': teacher.state_dict(),

@@ -111,7 +111,8 @@ def main():
         if i == args.steps - 1 and rank == 0 and not args.no_kernel_timing:
             # HIP events around every recurrence launch (same stream), in the LAST timed step only: recorded in
             # every step they cost 0.25 ms per step (70 event records between dependent launches)
-            cabi.lstm_profile_enable(True)
+            train_plan = [pl for pl in model.lstm.all_plans() if pl.training][0]
+            train_plan.profile_enable(True)
         loss = step(args.warmup + i)
         step_losses.append(loss)
     if world > 1:
@@ -146,7 +147,7 @@ def main():
         if not args.no_kernel_timing:
             # dominant kernel = the recurrence kernel with the larger total time in the step; its average launch
             # duration comes from HIP events recorded on the launch stream around its launches of the LAST timed step
-            pr = cabi.lstm_profile_read()
+            pr = train_plan.profile_read()
             peak = MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else 157.3
             us = {k: (1e3 * pr[k + "_ms"] / max(1, pr[k + "_launches"])) for k in ("fwd", "bwd")}
             dom = "bwd" if pr["bwd_ms"] >= pr["fwd_ms"] else "fwd"      # largest total time in the step

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CSN_LIB_PATH") or os.path.join(_HERE, "lib", "libcsn_hip.so")
 
 CSN_F32, CSN_BF16 = 0, 1
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _c_void_p, _c_int, _c_i64, _c_size_t, _c_float = (ctypes.c_void_p, ctypes.c_int, ctypes.c_int64,
                                                   ctypes.c_size_t, ctypes.c_float)
@@ -35,19 +35,26 @@ SIGNATURES = {
     "csn_eeg_filtfilt_scratch_bytes": (_c_size_t, [_c_int, _c_int, _c_int, _c_int]),
     "csn_eeg_filtfilt": (_c_int, [_c_void_p, _c_int, _c_int, _c_int, ctypes.POINTER(ctypes.c_double), _c_int,
                                   _c_void_p, _c_void_p, _c_void_p]),
+    "csn_lstm_plan_create": (_c_int, [ctypes.POINTER(LstmDesc), _c_int, ctypes.POINTER(_c_void_p)]),
+    "csn_lstm_plan_destroy": (None, [_c_void_p]),
+    "csn_lstm_plan_workspace_bytes": (_c_size_t, [_c_void_p]),
+    "csn_lstm_plan_path": (_c_int, [_c_void_p]),
     "csn_lstm_workspace_bytes": (_c_size_t, [ctypes.POINTER(LstmDesc), _c_int]),
-    "csn_lstm_forward": (_c_int, [ctypes.POINTER(LstmDesc), _c_void_p, _c_i64, _c_i64,
+    "csn_lstm_forward": (_c_int, [_c_void_p, _c_void_p, _c_i64, _c_i64,
                                   ctypes.POINTER(_c_void_p), ctypes.POINTER(_c_void_p),
                                   ctypes.POINTER(_c_void_p), ctypes.POINTER(_c_void_p),
-                                  _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p]),
-    "csn_lstm_backward": (_c_int, [ctypes.POINTER(LstmDesc), _c_void_p, _c_void_p, _c_void_p,
+                                  _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
+    "csn_lstm_backward": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p,
                                    ctypes.POINTER(_c_void_p), ctypes.POINTER(_c_void_p),
                                    ctypes.POINTER(_c_void_p), ctypes.POINTER(_c_void_p),
                                    _c_void_p, _c_void_p]),
-    "csn_lstm_read_status": (_c_int, [ctypes.POINTER(LstmDesc), _c_void_p, _c_int, ctypes.POINTER(_c_int)]),
-    "csn_lstm_profile_enable": (_c_int, [_c_int]),
-    "csn_lstm_profile_read": (_c_int, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_c_int), ctypes.POINTER(_c_int),
-                                       ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_c_int), ctypes.POINTER(_c_int)]),
+    "csn_lstm_status_clear": (_c_int, [_c_void_p, _c_void_p, _c_void_p]),
+    "csn_lstm_status_read": (_c_int, [_c_void_p, _c_void_p, ctypes.POINTER(_c_int)]),
+    "csn_lstm_status_raise": (_c_int, [_c_void_p, _c_void_p, _c_void_p]),
+    "csn_lstm_profile_enable": (_c_int, [_c_void_p, _c_int]),
+    "csn_lstm_profile_read": (_c_int, [_c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_c_int),
+                                       ctypes.POINTER(_c_int), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_c_int),
+                                       ctypes.POINTER(_c_int)]),
     "csn_gemm_nt": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_i64, _c_i64, _c_i64,
                              _c_int, _c_int, _c_int, _c_void_p]),
     "csn_gemm_tn_scratch_bytes": (_c_size_t, [_c_i64, _c_i64, _c_i64]),
@@ -208,24 +215,38 @@ def _ptr_array(tensors):
 
 
 class LstmPlan:
-    """Shapes + workspace of one stacked-LSTM problem; forward()/backward() enqueue on the current stream."""
+    """One stacked-LSTM problem: a native plan handle (csn_lstm_plan_create: layout, switches, side streams, events
+    -- all per plan, the library has no global state) + one workspace; forward()/backward() enqueue on the
+    current stream."""
 
     def __init__(self, B, T, I, H, L, dtype, device, training=True):
         self.desc = LstmDesc(B, T, I, H, L, _dt(dtype))
         self.training = bool(training)
+        self.device = torch.device(device)
         lib = load()
-        nbytes = lib.csn_lstm_workspace_bytes(ctypes.byref(self.desc), int(self.training))
-        if nbytes == 0:
-            raise CsnError(f"csn_lstm_workspace_bytes failed: {lib.csn_last_error().decode()}")
-        self.workspace = torch.empty(nbytes + 256, dtype=torch.uint8, device=device)
+        handle = _c_void_p()
+        with torch.cuda.device(self.device):
+            _check(lib.csn_lstm_plan_create(ctypes.byref(self.desc), int(self.training), ctypes.byref(handle)))
+        self._plan = handle
+        nbytes = lib.csn_lstm_plan_workspace_bytes(self._plan)
+        self.workspace = torch.empty(nbytes + 256, dtype=torch.uint8, device=self.device)
         off = (-self.workspace.data_ptr()) % 256
         self._ws_ptr = ctypes.c_void_p(self.workspace.data_ptr() + off)
-        self.device = device
         self.busy = False
+        self.clear_status()          # torch.empty memory: the sticky status word starts at 0
+
+    def __del__(self):
+        plan, self._plan = getattr(self, "_plan", None), None
+        if plan and _lib is not None:
+            _lib.csn_lstm_plan_destroy(plan)
 
     def key(self):
         d = self.desc
         return (d.B, d.T, d.I, d.H, d.L, d.dtype, self.training)
+
+    def path(self):
+        """0 generic cells, 1 per-diagonal bf16 launches, 2 weight-stationary forward, 3 + weight-stationary backward."""
+        return load().csn_lstm_plan_path(self._plan)
 
     def forward(self, x_bti, w_ih, w_hh, b_ih, b_hh, want_all=False):
         d = self.desc
@@ -239,41 +260,54 @@ class LstmPlan:
         for group in ws:
             for p in group:
                 assert p.dtype == torch.float32 and p.is_contiguous() and p.is_cuda
-        _check(load().csn_lstm_forward(ctypes.byref(d), _ptr(x_bti), x_bti.stride(0), x_bti.stride(1),
-                                       _ptr_array(ws[0]), _ptr_array(ws[1]), _ptr_array(ws[2]), _ptr_array(ws[3]),
-                                       self._ws_ptr, int(self.training), _ptr(y_last), _ptr(y_all), _stream()))
+        with torch.cuda.device(self.device):
+            _check(load().csn_lstm_forward(self._plan, _ptr(x_bti), x_bti.stride(0), x_bti.stride(1),
+                                           _ptr_array(ws[0]), _ptr_array(ws[1]), _ptr_array(ws[2]), _ptr_array(ws[3]),
+                                           self._ws_ptr, _ptr(y_last), _ptr(y_all), _stream()))
         return y_last, y_all
-
-    def status(self):
-        """Blocking: 0 if the last forward's in-kernel hand-offs all completed."""
-        out = _c_int(0)
-        _check(load().csn_lstm_read_status(ctypes.byref(self.desc), self._ws_ptr, int(self.training), ctypes.byref(out)))
-        return out.value
 
     def backward(self, dy_last, dy_all, grads, dx=None):
         """grads: 4 lists (dw_ih, dw_hh, db_ih, db_hh) of float32 device tensors, overwritten."""
-        d = self.desc
         if dy_last is not None:
             dy_last = dy_last.float().contiguous()
         if dy_all is not None:
             dy_all = dy_all.float().contiguous()
-        _check(load().csn_lstm_backward(ctypes.byref(d), _ptr(dy_last), _ptr(dy_all), self._ws_ptr,
-                                        _ptr_array(grads[0]), _ptr_array(grads[1]), _ptr_array(grads[2]),
-                                        _ptr_array(grads[3]), _ptr(dx), _stream()))
+        with torch.cuda.device(self.device):
+            _check(load().csn_lstm_backward(self._plan, _ptr(dy_last), _ptr(dy_all), self._ws_ptr,
+                                            _ptr_array(grads[0]), _ptr_array(grads[1]), _ptr_array(grads[2]),
+                                            _ptr_array(grads[3]), _ptr(dx), _stream()))
 
+    # ---- sticky status word of the workspace ------------------------------------------------------
+    def clear_status(self):
+        with torch.cuda.device(self.device):
+            _check(load().csn_lstm_status_clear(self._plan, self._ws_ptr, _stream()))
 
-def lstm_profile_enable(on=True):
-    _check(load().csn_lstm_profile_enable(int(on)))
+    def inject_timeout(self):
+        """Test hook: leaves the status word as a timed-out in-kernel wait would."""
+        with torch.cuda.device(self.device):
+            _check(load().csn_lstm_status_raise(self._plan, self._ws_ptr, _stream()))
 
+    def status(self, clear=False):
+        """Blocking: 0 if every in-kernel hand-off since the last clear completed (the word is sticky: a time-out
+        in ANY forward / backward since then keeps it raised)."""
+        out = _c_int(0)
+        _check(load().csn_lstm_status_read(self._plan, self._ws_ptr, ctypes.byref(out)))
+        if clear and out.value != 0:
+            self.clear_status()
+        return out.value
 
-def lstm_profile_read():
-    """-> dict(fwd_ms, fwd_launches, fwd_cells, bwd_ms, bwd_launches, bwd_cells) of the last fwd/bwd."""
-    fm, bm = ctypes.c_double(), ctypes.c_double()
-    fl, fc, bl, bc = _c_int(), _c_int(), _c_int(), _c_int()
-    _check(load().csn_lstm_profile_read(ctypes.byref(fm), ctypes.byref(fl), ctypes.byref(fc),
-                                        ctypes.byref(bm), ctypes.byref(bl), ctypes.byref(bc)))
-    return dict(fwd_ms=fm.value, fwd_launches=fl.value, fwd_cells=fc.value,
-                bwd_ms=bm.value, bwd_launches=bl.value, bwd_cells=bc.value)
+    # ---- per-plan event timing of the recurrence launches -----------------------------------------
+    def profile_enable(self, on=True):
+        _check(load().csn_lstm_profile_enable(self._plan, int(on)))
+
+    def profile_read(self):
+        """-> dict(fwd_ms, fwd_launches, fwd_cells, bwd_ms, bwd_launches, bwd_cells) of the last fwd/bwd."""
+        fm, bm = ctypes.c_double(), ctypes.c_double()
+        fl, fc, bl, bc = _c_int(), _c_int(), _c_int(), _c_int()
+        _check(load().csn_lstm_profile_read(self._plan, ctypes.byref(fm), ctypes.byref(fl), ctypes.byref(fc),
+                                            ctypes.byref(bm), ctypes.byref(bl), ctypes.byref(bc)))
+        return dict(fwd_ms=fm.value, fwd_launches=fl.value, fwd_cells=fc.value,
+                    bwd_ms=bm.value, bwd_launches=bl.value, bwd_cells=bc.value)
 
 
 def cosine_loss(student, teacher, want_grad=True, grad_scale=1.0):

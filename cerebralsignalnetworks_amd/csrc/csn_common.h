@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
+#include <atomic>
 #include <string>
 
 #include "../../include/csn_hip.h"
@@ -40,7 +42,64 @@ int fail(int status, const char* fmt, ...);
     if (!(cond)) return ::csn::fail(CSN_ERR_INVALID_ARGUMENT, __VA_ARGS__);              \
   } while (0)
 
+// ---- diagnostic switches --------------------------------------------
+// None is needed in production.  They are read from the environment into this struct -- once per LSTM plan
+// (csn_lstm_plan_create) or once per call of a stateless entry point -- and passed down by reference: the
+// library keeps no mutable global state, so plans on different streams / threads / devices never share any.
+struct Options {
+  bool cell_v1, no_persist, no_persist_bwd, persist_streams, no_xcd_local, no_rotate, no_fuse_x, no_beside,
+      no_side_stream, gemm_slot, gemm_no_dma, gemm_no_256, gemm_generic, gemm_lds64, tn_no_tr, filter_v1;
+  int chunk;       // timesteps per weight-stationary launch
+  int tn_stages;   // LDS-DMA ring depth of the 256 x 256 weight-gradient kernel
+  int fwd_nk;
+};
+static inline Options options_from_env() {
+  auto on = [](const char* name) { return getenv(name) != nullptr; };
+  auto num = [](const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+  };
+  Options o{};
+  o.cell_v1 = on("CSN_CELL_V1");
+  o.no_persist = on("CSN_NO_PERSIST");
+  o.no_persist_bwd = on("CSN_NO_PERSIST_BWD");
+  o.persist_streams = on("CSN_PERSIST_STREAMS");
+  o.no_xcd_local = on("CSN_NO_XCD_LOCAL");
+  o.no_rotate = on("CSN_NO_ROTATE");
+  o.no_fuse_x = on("CSN_NO_FUSE_X");
+  o.no_beside = on("CSN_NO_BESIDE");
+  o.no_side_stream = on("CSN_NO_SIDE_STREAM");
+  o.gemm_slot = on("CSN_GEMM_SLOT");
+  o.gemm_no_dma = on("CSN_GEMM_NO_DMA");
+  o.gemm_no_256 = on("CSN_GEMM_NO_256");
+  o.gemm_generic = on("CSN_GEMM_GENERIC");
+  o.gemm_lds64 = on("CSN_GEMM_LDS64");
+  o.tn_no_tr = on("CSN_TN_NO_TR");
+  o.filter_v1 = on("CSN_FILTER_V1");
+  o.chunk = num("CSN_LSTM_CHUNK", 32);
+  if (o.chunk < 1) o.chunk = 1;
+  o.tn_stages = num("CSN_TN_STAGES", 4);
+  o.fwd_nk = num("CSN_FWD_NK", 1);
+  return o;
+}
+
 static inline hipStream_t as_stream(csnStream_t s) { return reinterpret_cast<hipStream_t>(s); }
+// A kernel that uses more than 64 KB of dynamic LDS needs hipFuncAttributeMaxDynamicSharedMemorySize raised once
+// per DEVICE.  One bit per device in a per-kernel atomic word: idempotent, so a race between two threads only
+// sets the attribute twice.
+template <auto Kernel>
+static int ensure_dyn_lds(int bytes) {
+  static std::atomic<unsigned> done{0u};
+  int dev = 0;
+  CSN_HIP_CHECK(hipGetDevice(&dev));
+  const unsigned bit = 1u << (dev & 31);
+  if ((done.load(std::memory_order_acquire) & bit) == 0u) {
+    CSN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(Kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    done.fetch_or(bit, std::memory_order_release);
+  }
+  return CSN_OK;
+}
+
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 static inline size_t dtype_size(int dtype) { return dtype == CSN_BF16 ? 2 : 4; }
 
@@ -77,6 +136,10 @@ int launch_colsum_partial(const void* X, int64_t R, int64_t N, int dtype, void* 
 int launch_gemm_nt_beside(const void* A, const void* Bt, const float* bias, float* C, int64_t M, int64_t N, int64_t K,
                           int max_wgs, hipStream_t st);
 int launch_gemm_tn_slabs(const void* A, const void* B, float* slabs, int64_t M, int64_t N, int64_t K, int dtype,
-                         hipStream_t st, int* S_out, float* colsum, int* colsum_done);
+                         hipStream_t st, int* S_out, float* colsum, int* colsum_done, const Options& opt);
+// C[M,N] (+)= A[M,K] Bt[N,K]^T (+ bias): the body of csn_gemm_nt with the switches passed in
+int gemm_nt(const void* A, const void* Bt, const float* bias, void* C, int64_t M, int64_t N, int64_t K, int dtype,
+            int out_dtype, int accumulate, hipStream_t st, const Options& opt);
+size_t gemm_tn_scratch_bytes(int64_t M, int64_t N, int64_t K, const Options& opt);
 
 }  // namespace csn

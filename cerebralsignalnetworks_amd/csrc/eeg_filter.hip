@@ -371,7 +371,7 @@ extern "C" int csn_eeg_bandpass_znorm(const float* x, int B, int C, int T, const
     p.c[s][4] = sos[s * 6 + 5] / a0;
   }
   hipStream_t st = as_stream(stream);
-  if (T <= kScanChunks * kScanLen && nsec <= 5 && getenv("CSN_FILTER_V1") == nullptr) {
+  if (T <= kScanChunks * kScanLen && nsec <= 5 && !options_from_env().filter_v1) {
     switch (nsec) {
       case 0: return launch_scan<0>(x, y, B, C, T, p, ddof, out_dtype, time_major, st);
       case 1: return launch_scan<1>(x, y, B, C, T, p, ddof, out_dtype, time_major, st);

@@ -806,12 +806,6 @@ gemm_tn_256_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ Bm, 
   }
 }
 
-template <typename K>
-static int ensure_dyn_lds(K kernel, int bytes) {
-  CSN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-  return CSN_OK;
-}
-
 static int tn_splits(int64_t M, int64_t N, int64_t K) {
   const int64_t tiles = ((M + 127) / 128) * ((N + 127) / 128);
   int64_t s = (1024 + tiles - 1) / tiles;          // aim at >= 4 workgroups per CU
@@ -822,9 +816,8 @@ static int tn_splits(int64_t M, int64_t N, int64_t K) {
   return (int)s;
 }
 // the 256 x 256 kernel: one workgroup per CU (128 KB of LDS), so the K splits fill the 256 CUs once
-static bool tn_use_256(int64_t M, int64_t N, int64_t K) {
-  return M >= 256 && N >= 256 && K % 64 == 0 && K >= 8192 && getenv("CSN_GEMM_NO_DMA") == nullptr &&
-         getenv("CSN_GEMM_NO_256") == nullptr;
+static bool tn_use_256(int64_t M, int64_t N, int64_t K, const Options& opt) {
+  return M >= 256 && N >= 256 && K % 64 == 0 && K >= 8192 && !opt.gemm_no_dma && !opt.gemm_no_256;
 }
 static int tn_splits_256(int64_t M, int64_t N, int64_t K) {
   const int64_t tiles = ((M + 255) / 256) * ((N + 255) / 256);
@@ -836,35 +829,25 @@ static int tn_splits_256(int64_t M, int64_t N, int64_t K) {
   return (int)s;
 }
 
-}  // namespace csn
-
-using namespace csn;
-
-extern "C" int csn_gemm_nt(const void* A, const void* Bt, const float* bias, void* C, int64_t M, int64_t N, int64_t K,
-                           int dtype, int out_dtype, int accumulate, csnStream_t stream) {
+int gemm_nt(const void* A, const void* Bt, const float* bias, void* C, int64_t M, int64_t N, int64_t K, int dtype,
+            int out_dtype, int accumulate, hipStream_t st, const Options& opt) {
   CSN_REQUIRE(A && Bt && C, "csn_gemm_nt: null pointer");
   CSN_REQUIRE(M > 0 && N > 0 && K > 0, "csn_gemm_nt: bad shape M=%lld N=%lld K=%lld", (long long)M, (long long)N,
               (long long)K);
   CSN_REQUIRE(dtype == CSN_F32 || dtype == CSN_BF16, "csn_gemm_nt: bad dtype %d", dtype);
   CSN_REQUIRE(out_dtype == CSN_F32 || out_dtype == CSN_BF16, "csn_gemm_nt: bad out_dtype %d", out_dtype);
   CSN_REQUIRE(!(accumulate && out_dtype != CSN_F32), "csn_gemm_nt: accumulate needs a float32 C");
-  hipStream_t st = as_stream(stream);
   const bool fast = dtype == CSN_BF16 && (K % 8 == 0) && (N % 4 == 0) &&
                     ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(Bt) |
                       reinterpret_cast<uintptr_t>(C) | reinterpret_cast<uintptr_t>(bias)) & 15) == 0 &&
-                    getenv("CSN_GEMM_GENERIC") == nullptr;
+                    !opt.gemm_generic;
   if (!fast)
     return launch_generic(A, K, 1, Bt, 1, K, bias, C, N, M, N, K, dtype, out_dtype, accumulate, 1, 0, st);
   // 256 x 128 tiles where the tile count still fills the chip a few times over (measured at the LSTM's chunk
   // shapes: 58 vs 67 us at N = 3072, 56 vs 51 us at N = 768)
-  if (K % 64 == 0 && K >= 256 && M >= 256 && N >= 1024 && getenv("CSN_GEMM_NO_DMA") == nullptr &&
-      getenv("CSN_GEMM_NO_256") == nullptr) {
-    static bool attr_done = false;
-    if (!attr_done) {
-      if (int rc = ensure_dyn_lds(&gemm_nt_256_kernel<bf16_t, 3>, 3 * 49152)) return rc;
-      if (int rc = ensure_dyn_lds(&gemm_nt_256_kernel<float, 3>, 3 * 49152)) return rc;
-      attr_done = true;
-    }
+  if (K % 64 == 0 && K >= 256 && M >= 256 && N >= 1024 && !opt.gemm_no_dma && !opt.gemm_no_256) {
+    if (int rc = ensure_dyn_lds<&gemm_nt_256_kernel<bf16_t, 3>>(3 * 49152)) return rc;
+    if (int rc = ensure_dyn_lds<&gemm_nt_256_kernel<float, 3>>(3 * 49152)) return rc;
     dim3 grid256((unsigned)(((N + 127) / 128) * ((M + 255) / 256)));
     if (out_dtype == CSN_BF16)
       gemm_nt_256_kernel<bf16_t, 3><<<grid256, 512, 3 * 49152, st>>>((const bf16_t*)A, (const bf16_t*)Bt, bias, (bf16_t*)C, M, N, K, 0);
@@ -874,13 +857,9 @@ extern "C" int csn_gemm_nt(const void* A, const void* Bt, const float* bias, voi
     return CSN_OK;
   }
   dim3 grid((unsigned)(((N + 127) / 128) * ((M + 127) / 128)));
-  if (K % 64 == 0 && getenv("CSN_GEMM_NO_DMA") == nullptr) {
-    static bool attr_done = false;
-    if (!attr_done) {
-      if (int rc = ensure_dyn_lds(&gemm_nt_dma_kernel<bf16_t>, 98304)) return rc;
-      if (int rc = ensure_dyn_lds(&gemm_nt_dma_kernel<float>, 98304)) return rc;
-      attr_done = true;
-    }
+  if (K % 64 == 0 && !opt.gemm_no_dma) {
+    if (int rc = ensure_dyn_lds<&gemm_nt_dma_kernel<bf16_t>>(98304)) return rc;
+    if (int rc = ensure_dyn_lds<&gemm_nt_dma_kernel<float>>(98304)) return rc;
     if (out_dtype == CSN_BF16)
       gemm_nt_dma_kernel<bf16_t><<<grid, 256, 65536, st>>>((const bf16_t*)A, (const bf16_t*)Bt, bias, (bf16_t*)C, M, N, K, 0);
     else
@@ -888,7 +867,7 @@ extern "C" int csn_gemm_nt(const void* A, const void* Bt, const float* bias, voi
     CSN_LAUNCH_CHECK();
     return CSN_OK;
   }
-  const bool two = getenv("CSN_GEMM_LDS64") != nullptr;
+  const bool two = opt.gemm_lds64;
   if (out_dtype == CSN_BF16) {
     if (two) gemm_nt_bf16_kernel<bf16_t, 2><<<grid, 256, 65536, st>>>((const bf16_t*)A, (const bf16_t*)Bt, bias, (bf16_t*)C, M, N, K, 0);
     else gemm_nt_bf16_kernel<bf16_t, 1><<<grid, 256, 32768, st>>>((const bf16_t*)A, (const bf16_t*)Bt, bias, (bf16_t*)C, M, N, K, 0);
@@ -900,18 +879,23 @@ extern "C" int csn_gemm_nt(const void* A, const void* Bt, const float* bias, voi
   return CSN_OK;
 }
 
+}  // namespace csn
+
+using namespace csn;
+
+extern "C" int csn_gemm_nt(const void* A, const void* Bt, const float* bias, void* C, int64_t M, int64_t N, int64_t K,
+                           int dtype, int out_dtype, int accumulate, csnStream_t stream) {
+  return gemm_nt(A, Bt, bias, C, M, N, K, dtype, out_dtype, accumulate, as_stream(stream), options_from_env());
+}
+
 namespace csn {
 // NT GEMM on at most `max_wgs` workgroups, each alone on its CU (96 KB of LDS requested), walking the 128 x 128
 // tiles: runs beside a persistent LSTM launch on the CUs that launch leaves idle.  bf16 operands, K % 64 == 0.
 int launch_gemm_nt_beside(const void* A, const void* Bt, const float* bias, float* C, int64_t M, int64_t N, int64_t K,
                           int max_wgs, hipStream_t st) {
   CSN_REQUIRE(K % 64 == 0 && N % 4 == 0 && max_wgs >= 1, "launch_gemm_nt_beside: unsupported shape");
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (int rc = ensure_dyn_lds(&gemm_nt_256_kernel<float, 3>, 3 * 49152)) return rc;
-    if (int rc = ensure_dyn_lds(&gemm_nt_dma_kernel<float>, 98304)) return rc;
-    attr_done = true;
-  }
+  if (int rc = ensure_dyn_lds<&gemm_nt_256_kernel<float, 3>>(3 * 49152)) return rc;
+  if (int rc = ensure_dyn_lds<&gemm_nt_dma_kernel<float>>(98304)) return rc;
   if (M >= 256 && N >= 128 && K >= 256) {
     // 256 x 128 tiles, 8 waves, 144 KB of LDS: alone on a CU this kernel runs at twice the rate of the 4-wave one
     const int64_t tiles = ((N + 127) / 128) * ((M + 255) / 256);
@@ -927,35 +911,36 @@ int launch_gemm_nt_beside(const void* A, const void* Bt, const float* bias, floa
 }
 }  // namespace csn
 
-extern "C" size_t csn_gemm_tn_scratch_bytes(int64_t M, int64_t N, int64_t K) {
+namespace csn {
+size_t gemm_tn_scratch_bytes(int64_t M, int64_t N, int64_t K, const Options& opt) {
   if (M <= 0 || N <= 0 || K <= 0) return 0;
-  const int a = tn_splits(M, N, K), b = tn_use_256(M, N, K) ? tn_splits_256(M, N, K) : 0;
+  const int a = tn_splits(M, N, K), b = tn_use_256(M, N, K, opt) ? tn_splits_256(M, N, K) : 0;
   return (size_t)(a > b ? a : b) * (size_t)M * (size_t)N * sizeof(float);
+}
+}  // namespace csn
+
+extern "C" size_t csn_gemm_tn_scratch_bytes(int64_t M, int64_t N, int64_t K) {
+  return gemm_tn_scratch_bytes(M, N, K, options_from_env());
 }
 
 namespace csn {
 // colsum (optional): device buffer of at least 64 * M floats; if the kernel that runs can produce the column sums
 // of A on the way (one partial row of M values per K split), *colsum_done is set to 1.
 int launch_gemm_tn_slabs(const void* A, const void* B, float* slabs, int64_t M, int64_t N, int64_t K, int dtype,
-                         hipStream_t st, int* S_out, float* colsum, int* colsum_done) {
+                         hipStream_t st, int* S_out, float* colsum, int* colsum_done, const Options& opt) {
   if (colsum_done) *colsum_done = 0;
   const bool aligned16 = ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15) == 0;
-  if (dtype == CSN_BF16 && (M % 8 == 0) && (N % 8 == 0) && aligned16 && tn_use_256(M, N, K)) {
+  if (dtype == CSN_BF16 && (M % 8 == 0) && (N % 8 == 0) && aligned16 && tn_use_256(M, N, K, opt)) {
     const int S2 = tn_splits_256(M, N, K);
     int64_t kper2 = (K + S2 - 1) / S2;
     kper2 = (kper2 + 63) / 64 * 64;
     *S_out = S2;
-    static bool attr_done = false;
-    if (!attr_done) {
-      if (int rc = ensure_dyn_lds(&gemm_tn_256_kernel<5, false>, 5 * 32768)) return rc;
-      if (int rc = ensure_dyn_lds(&gemm_tn_256_kernel<4, false>, 4 * 32768)) return rc;
-      if (int rc = ensure_dyn_lds(&gemm_tn_256_kernel<3, false>, 3 * 32768)) return rc;
-      if (int rc = ensure_dyn_lds(&gemm_tn_256_kernel<4, true>, 4 * 32768)) return rc;
-      attr_done = true;
-    }
+    if (int rc = ensure_dyn_lds<&gemm_tn_256_kernel<5, false>>(5 * 32768)) return rc;
+    if (int rc = ensure_dyn_lds<&gemm_tn_256_kernel<4, false>>(4 * 32768)) return rc;
+    if (int rc = ensure_dyn_lds<&gemm_tn_256_kernel<3, false>>(3 * 32768)) return rc;
+    if (int rc = ensure_dyn_lds<&gemm_tn_256_kernel<4, true>>(4 * 32768)) return rc;
     dim3 grid((unsigned)(((N + 255) / 256) * ((M + 255) / 256) * S2));
-    const char* ns = getenv("CSN_TN_STAGES");
-    const int nst = ns ? atoi(ns) : 4;
+    const int nst = opt.tn_stages;
     const bf16_t* Ab = (const bf16_t*)A;
     const bf16_t* Bb = (const bf16_t*)B;
     if (colsum) gemm_tn_256_kernel<4, true><<<grid, 512, 4 * 32768, st>>>(Ab, Bb, slabs, M, N, K, kper2, colsum);
@@ -972,10 +957,10 @@ int launch_gemm_tn_slabs(const void* A, const void* B, float* slabs, int64_t M, 
   *S_out = S;
   const bool fast = dtype == CSN_BF16 && (M % 8 == 0) && (N % 8 == 0) &&
                     ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15) == 0 &&
-                    getenv("CSN_GEMM_GENERIC") == nullptr;
+                    !opt.gemm_generic;
   if (fast) {
     dim3 grid((unsigned)(((N + 127) / 128) * ((M + 127) / 128) * S));
-    if (getenv("CSN_TN_NO_TR"))
+    if (opt.tn_no_tr)
       gemm_tn_bf16_kernel<false><<<grid, 256, 0, st>>>((const bf16_t*)A, (const bf16_t*)B, slabs, M, N, K, kper);
     else
       gemm_tn_bf16_kernel<true><<<grid, 256, 0, st>>>((const bf16_t*)A, (const bf16_t*)B, slabs, M, N, K, kper);
@@ -994,6 +979,6 @@ extern "C" int csn_gemm_tn(const void* A, const void* B, float* C, int64_t M, in
   CSN_REQUIRE(dtype == CSN_F32 || dtype == CSN_BF16, "csn_gemm_tn: bad dtype %d", dtype);
   hipStream_t st = as_stream(stream);
   int S = 1;
-  if (int rc = launch_gemm_tn_slabs(A, B, (float*)scratch, M, N, K, dtype, st, &S, nullptr, nullptr)) return rc;
+  if (int rc = launch_gemm_tn_slabs(A, B, (float*)scratch, M, N, K, dtype, st, &S, nullptr, nullptr, options_from_env())) return rc;
   return launch_reduce_slabs((const float*)scratch, M * N, S, C, M * N, 0, st);
 }

@@ -47,11 +47,11 @@ struct WsLayout {
   bool il, persist, persist_bwd;
 };
 
-static WsLayout make_layout(const csnLstmDesc& d, int training) {
+static WsLayout make_layout(const csnLstmDesc& d, int training, const Options& opt) {
   WsLayout w{};
-  w.il = cell_blk_supported(d.H, d.dtype);
-  w.persist = w.il && fwd_persist_supported(d.B, d.H, d.dtype) && d.L <= 4;
-  w.persist_bwd = w.persist && training && bwd_persist_supported(d.B, d.H, d.dtype);
+  w.il = cell_blk_supported(d.H, d.dtype, opt);
+  w.persist = w.il && fwd_persist_supported(d.B, d.H, d.dtype, opt) && d.L <= 4;
+  w.persist_bwd = w.persist && training && bwd_persist_supported(d.B, d.H, d.dtype, opt);
   size_t off = 0;
   const size_t es = dtype_size(d.dtype);
   auto take = [&](size_t bytes) {
@@ -98,14 +98,14 @@ static WsLayout make_layout(const csnLstmDesc& d, int training) {
         L.bflags = take((size_t)d.T * (Bpad / 64) * kPersistFlagLine * 4);
       }
     }
-    size_t a = csn_gemm_tn_scratch_bytes(G, I, TB), b = csn_gemm_tn_scratch_bytes(G, H, TB);
+    size_t a = gemm_tn_scratch_bytes(G, I, TB, opt), b = gemm_tn_scratch_bytes(G, H, TB, opt);
     if (a > tn_bytes) tn_bytes = a;
     if (b > tn_bytes) tn_bytes = b;
   }
   w.x_c = take(TB * d.I * es);
   w.status = take(256);
   // (H = 512 excluded: its 64 x 32-unit tile leaves no registers for the W_ih fragments)
-  w.fuse_x = w.persist && d.I % 32 == 0 && d.I <= 128 && d.H != 512 && getenv("CSN_NO_FUSE_X") == nullptr;
+  w.fuse_x = w.persist && d.I % 32 == 0 && d.I <= 128 && d.H != 512 && !opt.no_fuse_x;
   if (w.fuse_x) {
     w.x_blk = take((size_t)d.T * Bpad * d.I * 2);
     w.wih0_blk = take(G * d.I * 2);
@@ -172,26 +172,20 @@ static inline unsigned grid_for(int64_t n) {
   return (unsigned)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
 }
 
-// ---- second stream + event pool (library-owned, created on first use, per device) ------------
+// ---- second stream + event pool: owned by the PLAN (created on first use, destroyed with it) -------
 struct SideCtx {
   hipStream_t side = nullptr;           // GEMMs
   hipStream_t layer[8] = {nullptr};     // weight-stationary forward: one stream per layer >= 1
   std::vector<hipEvent_t> events;
   size_t next = 0;
 };
-static SideCtx g_side[16];
 
-static int side_ctx(SideCtx** out) {
-  int dev = 0;
-  CSN_HIP_CHECK(hipGetDevice(&dev));
-  CSN_REQUIRE(dev >= 0 && dev < 16, "device index %d out of range", dev);
-  SideCtx& c = g_side[dev];
+static int side_ctx(SideCtx& c) {
   if (c.side == nullptr) {
     CSN_HIP_CHECK(hipStreamCreateWithFlags(&c.side, hipStreamNonBlocking));
     for (int l = 1; l < 8; ++l) CSN_HIP_CHECK(hipStreamCreateWithFlags(&c.layer[l], hipStreamNonBlocking));
   }
   c.next = 0;
-  *out = &c;
   return CSN_OK;
 }
 static int next_event(SideCtx* c, hipEvent_t* ev) {
@@ -223,8 +217,7 @@ struct Prof {
   std::vector<hipEvent_t> pair[2];
   size_t pairs_used[2] = {0, 0};
 };
-static Prof g_prof;
-static int prof_mark(int which, hipStream_t st) {
+static int prof_mark(Prof& g_prof, int which, hipStream_t st) {
   if (!g_prof.on) return CSN_OK;
   if ((which & 1) == 0) g_prof.pairs_used[which >> 1] = 0;
   if (g_prof.ev[which] == nullptr) CSN_HIP_CHECK(hipEventCreate(&g_prof.ev[which]));
@@ -232,7 +225,7 @@ static int prof_mark(int which, hipStream_t st) {
   return CSN_OK;
 }
 
-static int prof_pair(int k, bool end, hipStream_t st) {   // k: 0 forward, 1 backward
+static int prof_pair(Prof& g_prof, int k, bool end, hipStream_t st) {   // k: 0 forward, 1 backward
   if (!g_prof.on) return CSN_OK;
   const size_t i = 2 * g_prof.pairs_used[k] + (end ? 1 : 0);
   while (g_prof.pair[k].size() <= i) {
@@ -245,26 +238,76 @@ static int prof_pair(int k, bool end, hipStream_t st) {   // k: 0 forward, 1 bac
   return CSN_OK;
 }
 
-static int chunk_steps() {
-  const char* e = getenv("CSN_LSTM_CHUNK");
-  int c = e ? atoi(e) : 32;
-  return c < 1 ? 1 : c;
-}
-
 }  // namespace csn
 
-using namespace csn;
+// The plan: shapes, the switches read once at creation, the workspace layout, and every piece of host-side
+// state a forward / backward needs (side streams, event pool, profiling events).  Nothing of it is global, so
+// plans are independent: one per (stream, thread, device) as the caller likes.  A plan is not itself
+// thread-safe -- do not call the same plan from two threads at once.
+struct csnLstmPlan {
+  csnLstmDesc d;
+  int training;
+  int device;
+  csn::Options opt;
+  csn::WsLayout w;
+  csn::SideCtx sc;
+  csn::Prof prof;
+};
 
-extern "C" int csn_lstm_profile_enable(int on) {
-  g_prof.on = on != 0;
-  g_prof.have[0] = g_prof.have[1] = false;
+using namespace csn;
+typedef csnLstmPlan Plan;
+
+extern "C" int csn_lstm_plan_create(const csnLstmDesc* d, int training, csnLstmPlan** out) {
+  if (int rc = check_desc("csn_lstm_plan_create", d)) return rc;
+  CSN_REQUIRE(out != nullptr, "csn_lstm_plan_create: null output pointer");
+  Plan* P = new Plan();
+  P->d = *d;
+  P->training = training != 0;
+  if (hipGetDevice(&P->device) != hipSuccess) {
+    delete P;
+    return fail(CSN_ERR_HIP, "csn_lstm_plan_create: hipGetDevice failed");
+  }
+  P->opt = options_from_env();
+  P->w = make_layout(*d, P->training, P->opt);
+  *out = P;
   return CSN_OK;
 }
 
-extern "C" int csn_lstm_profile_read(double* fwd_ms, int* fwd_launches, int* fwd_cells, double* bwd_ms,
+extern "C" void csn_lstm_plan_destroy(csnLstmPlan* P) {
+  if (P == nullptr) return;
+  int cur = 0;
+  const bool switched = hipGetDevice(&cur) == hipSuccess && cur != P->device && hipSetDevice(P->device) == hipSuccess;
+  for (hipEvent_t e : P->sc.events) (void)hipEventDestroy(e);
+  if (P->sc.side) (void)hipStreamDestroy(P->sc.side);
+  for (int l = 1; l < 8; ++l)
+    if (P->sc.layer[l]) (void)hipStreamDestroy(P->sc.layer[l]);
+  for (int i = 0; i < 4; ++i)
+    if (P->prof.ev[i]) (void)hipEventDestroy(P->prof.ev[i]);
+  for (int k = 0; k < 2; ++k)
+    for (hipEvent_t e : P->prof.pair[k]) (void)hipEventDestroy(e);
+  if (switched) (void)hipSetDevice(cur);
+  delete P;
+}
+
+extern "C" size_t csn_lstm_plan_workspace_bytes(const csnLstmPlan* P) { return P ? P->w.total : 0; }
+
+extern "C" int csn_lstm_plan_path(const csnLstmPlan* P) {
+  if (P == nullptr) return -1;
+  return P->w.persist_bwd ? 3 : (P->w.persist ? 2 : (P->w.il ? 1 : 0));
+}
+
+extern "C" int csn_lstm_profile_enable(csnLstmPlan* P, int on) {
+  CSN_REQUIRE(P != nullptr, "csn_lstm_profile_enable: null plan");
+  P->prof.on = on != 0;
+  P->prof.have[0] = P->prof.have[1] = false;
+  return CSN_OK;
+}
+
+extern "C" int csn_lstm_profile_read(csnLstmPlan* P, double* fwd_ms, int* fwd_launches, int* fwd_cells, double* bwd_ms,
                                      int* bwd_launches, int* bwd_cells) {
-  CSN_REQUIRE(fwd_ms && fwd_launches && fwd_cells && bwd_ms && bwd_launches && bwd_cells,
+  CSN_REQUIRE(P && fwd_ms && fwd_launches && fwd_cells && bwd_ms && bwd_launches && bwd_cells,
               "csn_lstm_profile_read: null pointer");
+  Prof& g_prof = P->prof;
   *fwd_ms = *bwd_ms = 0.0;
   *fwd_launches = *fwd_cells = *bwd_launches = *bwd_cells = 0;
   for (int k = 0; k < 2; ++k) {
@@ -287,27 +330,46 @@ extern "C" int csn_lstm_profile_read(double* fwd_ms, int* fwd_launches, int* fwd
   return CSN_OK;
 }
 
-extern "C" int csn_lstm_read_status(const csnLstmDesc* d, const void* workspace, int training, int* status) {
-  if (int rc = check_desc("csn_lstm_read_status", d)) return rc;
-  CSN_REQUIRE(workspace && status, "csn_lstm_read_status: null pointer");
-  const WsLayout w = make_layout(*d, training);
+// The workspace's status word (sticky; see include/csn_hip.h)
+extern "C" int csn_lstm_status_clear(const csnLstmPlan* P, void* workspace, csnStream_t stream) {
+  CSN_REQUIRE(P && workspace, "csn_lstm_status_clear: null pointer");
+  CSN_HIP_CHECK(hipMemsetAsync((char*)workspace + P->w.status, 0, 256, as_stream(stream)));
+  return CSN_OK;
+}
+extern "C" int csn_lstm_status_raise(const csnLstmPlan* P, void* workspace, csnStream_t stream) {
+  CSN_REQUIRE(P && workspace, "csn_lstm_status_raise: null pointer");
+  CSN_HIP_CHECK(hipMemsetAsync((char*)workspace + P->w.status, 1, 1, as_stream(stream)));   // word = 1, as a timed-out wait leaves it
+  return CSN_OK;
+}
+extern "C" int csn_lstm_status_read(const csnLstmPlan* P, const void* workspace, int* status) {
+  CSN_REQUIRE(P && workspace && status, "csn_lstm_status_read: null pointer");
   unsigned flag = 0;
-  CSN_HIP_CHECK(hipMemcpy(&flag, (const char*)workspace + w.status, sizeof(flag), hipMemcpyDeviceToHost));
+  CSN_HIP_CHECK(hipMemcpy(&flag, (const char*)workspace + P->w.status, sizeof(flag), hipMemcpyDeviceToHost));
   *status = (int)flag;
   return CSN_OK;
 }
 
 extern "C" size_t csn_lstm_workspace_bytes(const csnLstmDesc* d, int training) {
   if (check_desc("csn_lstm_workspace_bytes", d) != CSN_OK) return 0;
-  return make_layout(*d, training).total;
+  return make_layout(*d, training, options_from_env()).total;
+}
+
+// C[M,N] = A[K,M]^T B[K,N] through the split-K slabs + their fixed-order reduction (the body of csn_gemm_tn)
+static int gemm_tn_full(const void* A, const void* B, float* C, int64_t M, int64_t N, int64_t K, int dtype, void* scratch,
+                        hipStream_t st, const Options& opt) {
+  int S = 1;
+  if (int rc = launch_gemm_tn_slabs(A, B, (float*)scratch, M, N, K, dtype, st, &S, nullptr, nullptr, opt)) return rc;
+  return launch_reduce_slabs((const float*)scratch, M * N, S, C, M * N, 0, st);
 }
 
 // =============================================================================================
 // v1 path
 // =============================================================================================
-static int forward_v1(const csnLstmDesc* d, const WsLayout& w, char* ws, const float* x, int64_t xsb, int64_t xst,
+static int forward_v1(Plan& P, char* ws, const float* x, int64_t xsb, int64_t xst,
                       const float* const* w_ih, const float* const* w_hh, const float* const* b_ih,
                       const float* const* b_hh, int training, csnStream_t stream) {
+  const csnLstmDesc* d = &P.d;
+  const WsLayout& w = P.w;
   hipStream_t st = as_stream(stream);
   const int B = d->B, T = d->T, H = d->H, dt = d->dtype;
   const int64_t G = 4 * (int64_t)H, TB = (int64_t)T * B;
@@ -326,8 +388,8 @@ static int forward_v1(const csnLstmDesc* d, const WsLayout& w, char* ws, const f
     if ((rc = launch_add_vec(b_ih[l], b_hh[l], (float*)(ws + L.bias), G, st))) return rc;
     const void* inp = l == 0 ? (const void*)(ws + w.x_c)
                              : (const void*)(ws + w.layer[l - 1].h_all + (size_t)B * H * es);
-    if ((rc = csn_gemm_nt(inp, ws + L.wih, (const float*)(ws + L.bias), ws + L.xproj, TB, G, I, dt, CSN_F32, 0,
-                          stream)))
+    if ((rc = gemm_nt(inp, ws + L.wih, (const float*)(ws + L.bias), ws + L.xproj, TB, G, I, dt, CSN_F32, 0,
+                          st, P.opt)))
       return rc;
     CSN_HIP_CHECK(hipMemsetAsync(ws + L.h_all, 0, (size_t)B * H * es, st));
     CSN_HIP_CHECK(hipMemsetAsync(ws + L.c_all, 0, (size_t)B * H * 4, st));
@@ -344,9 +406,11 @@ static int forward_v1(const csnLstmDesc* d, const WsLayout& w, char* ws, const f
   return CSN_OK;
 }
 
-static int backward_v1(const csnLstmDesc* d, const WsLayout& w, char* ws, const float* dy_last, const float* dy_tm,
+static int backward_v1(Plan& P, char* ws, const float* dy_last, const float* dy_tm,
                        float* const* dw_ih, float* const* dw_hh, float* const* db_ih, float* const* db_hh, float* dx,
                        csnStream_t stream) {
+  const csnLstmDesc* d = &P.d;
+  const WsLayout& w = P.w;
   hipStream_t st = as_stream(stream);
   const int B = d->B, T = d->T, H = d->H, dt = d->dtype;
   const int64_t G = 4 * (int64_t)H, TB = (int64_t)T * B;
@@ -369,12 +433,12 @@ static int backward_v1(const csnLstmDesc* d, const WsLayout& w, char* ws, const 
     }
     const void* inp = l == 0 ? (const void*)(ws + w.x_c)
                              : (const void*)(ws + w.layer[l - 1].h_all + (size_t)B * H * es);
-    if ((rc = csn_gemm_tn(ws + L.dgates, ws + L.h_all, dw_hh[l], G, H, TB, dt, ws + w.tn_scratch, stream))) return rc;
-    if ((rc = csn_gemm_tn(ws + L.dgates, inp, dw_ih[l], G, I, TB, dt, ws + w.tn_scratch, stream))) return rc;
+    if ((rc = gemm_tn_full(ws + L.dgates, ws + L.h_all, dw_hh[l], G, H, TB, dt, ws + w.tn_scratch, st, P.opt))) return rc;
+    if ((rc = gemm_tn_full(ws + L.dgates, inp, dw_ih[l], G, I, TB, dt, ws + w.tn_scratch, st, P.opt))) return rc;
     if ((rc = launch_colsum(ws + L.dgates, TB, G, dt, db_ih[l], ws + w.colsum, st))) return rc;
     CSN_HIP_CHECK(hipMemcpyAsync(db_hh[l], db_ih[l], (size_t)G * 4, hipMemcpyDeviceToDevice, st));
     if (l > 0 || dx) {
-      if ((rc = csn_gemm_nt(ws + L.dgates, ws + L.wiht, nullptr, ws + L.dx, TB, I, G, dt, CSN_F32, 0, stream)))
+      if ((rc = gemm_nt(ws + L.dgates, ws + L.wiht, nullptr, ws + L.dx, TB, I, G, dt, CSN_F32, 0, st, P.opt)))
         return rc;
       if (l == 0) {
         tb_to_bt_kernel<<<grid_for(TB * I), 256, 0, st>>>((const float*)(ws + L.dx), dx, B, T, (int)I);
@@ -388,21 +452,23 @@ static int backward_v1(const csnLstmDesc* d, const WsLayout& w, char* ws, const 
 // =============================================================================================
 // il fast path (wavefront over layers, GEMMs on the side stream)
 // =============================================================================================
-static int forward_persist(const csnLstmDesc* d, const WsLayout& w, char* ws, int training, hipStream_t st,
-                           SideCtx* sc, hipStream_t side);
+static int forward_persist(Plan& P, char* ws, int training, hipStream_t st, SideCtx* sc, hipStream_t side);
 
-static int forward_il(const csnLstmDesc* d, const WsLayout& w, char* ws, const float* x, int64_t xsb, int64_t xst,
+static int forward_il(Plan& P, char* ws, const float* x, int64_t xsb, int64_t xst,
                       const float* const* w_ih, const float* const* w_hh, const float* const* b_ih,
                       const float* const* b_hh, int training, csnStream_t stream) {
+  const csnLstmDesc* d = &P.d;
+  const WsLayout& w = P.w;
+  Prof& g_prof = P.prof;
   hipStream_t st = as_stream(stream);
-  SideCtx* sc;
+  SideCtx* sc = &P.sc;
   int rc;
-  if ((rc = side_ctx(&sc))) return rc;
-  hipStream_t side = getenv("CSN_NO_SIDE_STREAM") ? st : sc->side;
+  if ((rc = side_ctx(P.sc))) return rc;
+  hipStream_t side = P.opt.no_side_stream ? st : sc->side;
   const int B = d->B, T = d->T, H = d->H, NL = d->L;
   const int64_t G = 4 * (int64_t)H, TB = (int64_t)T * B;
   const size_t Bpad = ((size_t)B + 63) / 64 * 64;
-  const int Cz = chunk_steps(), lag = 2 * Cz;
+  const int Cz = P.opt.chunk, lag = 2 * Cz;
 
   if ((rc = launch_cast_strided(x, xsb, xst, B, T, d->I, ws + w.x_c, CSN_BF16, st))) return rc;
   for (int l = 0; l < NL; ++l) {
@@ -430,18 +496,18 @@ static int forward_il(const csnLstmDesc* d, const WsLayout& w, char* ws, const f
     if ((rc = launch_blockify(w_ih[0], d->I, 1, G, d->I, 1, 0, H, ws + w.wih0_blk, st))) return rc;
   } else {
     // layer 0 input projection for every step, main stream
-    if ((rc = csn_gemm_nt(ws + w.x_c, ws + w.layer[0].wih, (const float*)(ws + w.layer[0].bias), ws + w.layer[0].xproj,
-                          TB, G, d->I, CSN_BF16, CSN_F32, 0, stream)))
+    if ((rc = gemm_nt(ws + w.x_c, ws + w.layer[0].wih, (const float*)(ws + w.layer[0].bias), ws + w.layer[0].xproj,
+                          TB, G, d->I, CSN_BF16, CSN_F32, 0, st, P.opt)))
       return rc;
   }
-  if (w.persist) return forward_persist(d, w, ws, training, st, sc, side);
+  if (w.persist) return forward_persist(P, ws, training, st, sc, side);
   if (NL > 1 && (rc = hand_off(sc, st, side))) return rc;   // side stream sees the prepared weights
 
   const int nch = (T + Cz - 1) / Cz;
   std::vector<hipEvent_t> xproj_ready((size_t)NL * nch, nullptr);
   const int D = T + lag * (NL - 1);
   int n_launch = 0, n_cells = 0;
-  if ((rc = prof_mark(0, st))) return rc;
+  if ((rc = prof_mark(g_prof, 0, st))) return rc;
   for (int dg = 0; dg < D; ++dg) {
     CellFwdArgs a{};
     a.B = B;
@@ -463,7 +529,7 @@ static int forward_il(const csnLstmDesc* d, const WsLayout& w, char* ws, const f
       P.h_out_blk = (bf16_t*)(ws + L.hblk[(t + 1) & 1]);
     }
     if (np == 0) continue;
-    if ((rc = launch_cell_fwd_il(a, np, st))) return rc;
+    if ((rc = launch_cell_fwd_il(a, np, st, P.opt.fwd_nk))) return rc;
     ++n_launch;
     n_cells += np;
     // a layer that just finished a chunk feeds the next layer's input projection (side stream)
@@ -474,9 +540,9 @@ static int forward_il(const csnLstmDesc* d, const WsLayout& w, char* ws, const f
       const int c = t / Cz, t0 = c * Cz, nsteps = t - t0 + 1;
       if ((rc = hand_off(sc, st, side))) return rc;
       const LayerWs& Ln = w.layer[l + 1];
-      rc = csn_gemm_nt((const bf16_t*)(ws + w.layer[l].h_all) + (size_t)(t0 + 1) * B * H, ws + Ln.wih,
+      rc = gemm_nt((const bf16_t*)(ws + w.layer[l].h_all) + (size_t)(t0 + 1) * B * H, ws + Ln.wih,
                        (const float*)(ws + Ln.bias), (float*)(ws + Ln.xproj) + (size_t)t0 * B * G,
-                       (int64_t)nsteps * B, G, H, CSN_BF16, CSN_F32, 0, (csnStream_t)side);
+                       (int64_t)nsteps * B, G, H, CSN_BF16, CSN_F32, 0, side, P.opt);
       if (rc) return rc;
       hipEvent_t ev;
       if ((rc = next_event(sc, &ev))) return rc;
@@ -484,7 +550,7 @@ static int forward_il(const csnLstmDesc* d, const WsLayout& w, char* ws, const f
       xproj_ready[(size_t)(l + 1) * nch + c] = ev;
     }
   }
-  if ((rc = prof_mark(1, st))) return rc;
+  if ((rc = prof_mark(g_prof, 1, st))) return rc;
   g_prof.launches[0] = n_launch;
   g_prof.cells[0] = n_cells;
   g_prof.have[0] = g_prof.on;
@@ -502,12 +568,14 @@ static int forward_il(const csnLstmDesc* d, const WsLayout& w, char* ws, const f
 //
 // Stream form (any number of layers / M-tiles): layer l runs chunk after chunk on its own stream, the GEMMs
 // on the side stream, ordered by events; placement-independent hand-off.
-static int forward_persist(const csnLstmDesc* d, const WsLayout& w, char* ws, int training, hipStream_t st,
-                           SideCtx* sc, hipStream_t side) {
+static int forward_persist(Plan& P, char* ws, int training, hipStream_t st, SideCtx* sc, hipStream_t side) {
+  const csnLstmDesc* d = &P.d;
+  const WsLayout& w = P.w;
+  Prof& g_prof = P.prof;
   const int B = d->B, T = d->T, H = d->H, NL = d->L;
   const int64_t G = 4 * (int64_t)H;
   const int Bpad = (B + 63) / 64 * 64, MT = Bpad / 64;
-  const int Cz = chunk_steps();
+  const int Cz = P.opt.chunk;
   const int nch = (T + Cz - 1) / Cz;
   int rc;
   for (int l = 0; l < NL; ++l)
@@ -538,24 +606,24 @@ static int forward_persist(const csnLstmDesc* d, const WsLayout& w, char* ws, in
     const LayerWs& L = w.layer[l];
     const LayerWs& Ln = w.layer[l + 1];
     const int t0 = c * Cz, nsteps = (t0 + Cz <= T) ? Cz : T - t0;
-    return csn_gemm_nt((const bf16_t*)(ws + L.h_all) + (size_t)(t0 + 1) * B * H, ws + Ln.wih,
+    return gemm_nt((const bf16_t*)(ws + L.h_all) + (size_t)(t0 + 1) * B * H, ws + Ln.wih,
                        (const float*)(ws + Ln.bias), (float*)(ws + Ln.xproj) + (size_t)t0 * B * G,
-                       (int64_t)nsteps * B, G, H, CSN_BF16, CSN_F32, 0, (csnStream_t)on);
+                       (int64_t)nsteps * B, G, H, CSN_BF16, CSN_F32, 0, on, P.opt);
   };
   PersistFwdArgs a{};
   a.error_flag = (unsigned*)(ws + w.status);
   a.B = B; a.H = H; a.T = T; a.Bpad = Bpad; a.MT = MT;
-  a.rotate = getenv("CSN_NO_ROTATE") == nullptr;
+  a.rotate = !P.opt.no_rotate;
   int n_launch = 0;
 
   const int max_slots = NL < nch ? NL : nch;
   const bool grouped = max_slots <= 4 && max_slots * MT <= 8 && fwd_persist_slices(H) <= 32 &&
-                       getenv("CSN_PERSIST_STREAMS") == nullptr;
+                       !P.opt.persist_streams;
   if (grouped) {
     const int ndiag = nch + NL - 1;
-    const bool try_local = getenv("CSN_NO_XCD_LOCAL") == nullptr;
+    const bool try_local = !P.opt.no_xcd_local;
     if (try_local) CSN_HIP_CHECK(hipMemsetAsync(ws + w.agree, 0, (size_t)ndiag * 8 * sizeof(unsigned long long), st));
-    if ((rc = prof_mark(0, st))) return rc;
+    if ((rc = prof_mark(g_prof, 0, st))) return rc;
     for (int dg = 0; dg < ndiag; ++dg) {
       int lay[4], ns = 0;
       for (int l = 0; l < NL; ++l) {
@@ -567,20 +635,23 @@ static int forward_persist(const csnLstmDesc* d, const WsLayout& w, char* ws, in
       a.nslots = ns;
       a.xcd_groups = 1;
       a.agree = try_local ? (unsigned long long*)(ws + w.agree) + (size_t)dg * 8 : nullptr;
-      if ((rc = prof_pair(0, false, st))) return rc;
+      if ((rc = prof_pair(g_prof, 0, false, st))) return rc;
       if ((rc = launch_fwd_persist(a, st))) return rc;
-      if ((rc = prof_pair(0, true, st))) return rc;
+      if ((rc = prof_pair(g_prof, 0, true, st))) return rc;
       ++n_launch;
       for (int i = 0; i < ns; ++i)
         if (lay[i] + 1 < NL && (rc = xproj_gemm(lay[i], dg - lay[i], st))) return rc;
     }
-    if ((rc = prof_mark(1, st))) return rc;
+    if ((rc = prof_mark(g_prof, 1, st))) return rc;
     g_prof.launches[0] = n_launch;
     g_prof.cells[0] = T * NL;
     g_prof.have[0] = g_prof.on;
     return CSN_OK;
   }
 
+  // every launch needs ALL its workgroups resident (one per CU): layers on streams of their own may only run side
+  // by side while together they fit the chip; otherwise everything goes down the caller's stream, layer after layer
+  if (NL * fwd_persist_slices(H) * MT > 256) side = st;
   hipStream_t ls[8];
   ls[0] = st;
   for (int l = 1; l < NL; ++l) {
@@ -588,8 +659,8 @@ static int forward_persist(const csnLstmDesc* d, const WsLayout& w, char* ws, in
     if (ls[l] != st && (rc = hand_off(sc, st, ls[l]))) return rc;
   }
   if (side != st && (rc = hand_off(sc, st, side))) return rc;
-  const bool gemm_slot = getenv("CSN_GEMM_SLOT") != nullptr;
-  if ((rc = prof_mark(0, st))) return rc;
+  const bool gemm_slot = P.opt.gemm_slot;
+  if ((rc = prof_mark(g_prof, 0, st))) return rc;
   a.nslots = 1;
   a.xcd_groups = 0;
   a.agree = nullptr;
@@ -612,35 +683,38 @@ static int forward_persist(const csnLstmDesc* d, const WsLayout& w, char* ws, in
   for (int l = 1; l < NL; ++l)
     if (ls[l] != st && (rc = hand_off(sc, ls[l], st))) return rc;
   if (side != st && (rc = hand_off(sc, side, st))) return rc;
-  if ((rc = prof_mark(1, st))) return rc;
+  if ((rc = prof_mark(g_prof, 1, st))) return rc;
   g_prof.launches[0] = n_launch;
   g_prof.cells[0] = T * NL;
   g_prof.have[0] = g_prof.on;
   return CSN_OK;
 }
 
-static int backward_persist(const csnLstmDesc* d, const WsLayout& w, char* ws, const float* dy_last,
+static int backward_persist(Plan& P, char* ws, const float* dy_last,
                             const float* dy_tm, float* const* dw_ih, float* const* dw_hh, float* const* db_ih,
                             float* const* db_hh, float* dx, hipStream_t st);
 
-static int backward_il(const csnLstmDesc* d, const WsLayout& w, char* ws, const float* dy_last, const float* dy_tm,
+static int backward_il(Plan& P, char* ws, const float* dy_last, const float* dy_tm,
                        float* const* dw_ih, float* const* dw_hh, float* const* db_ih, float* const* db_hh, float* dx,
                        csnStream_t stream) {
+  const csnLstmDesc* d = &P.d;
+  const WsLayout& w = P.w;
+  Prof& g_prof = P.prof;
   hipStream_t st = as_stream(stream);
   if (w.persist_bwd) {
-    const int MTg = (d->B + 63) / 64, nchg = (d->T + chunk_steps() - 1) / chunk_steps();
+    const int MTg = (d->B + 63) / 64, nchg = (d->T + P.opt.chunk - 1) / P.opt.chunk;
     const int slots = d->L < nchg ? d->L : nchg;
-    if (slots <= 4 && slots * MTg <= 8 && getenv("CSN_PERSIST_STREAMS") == nullptr)
-      return backward_persist(d, w, ws, dy_last, dy_tm, dw_ih, dw_hh, db_ih, db_hh, dx, st);
+    if (slots <= 4 && slots * MTg <= 8 && !P.opt.persist_streams)
+      return backward_persist(P, ws, dy_last, dy_tm, dw_ih, dw_hh, db_ih, db_hh, dx, st);
   }
-  SideCtx* sc;
+  SideCtx* sc = &P.sc;
   int rc;
-  if ((rc = side_ctx(&sc))) return rc;
-  hipStream_t side = getenv("CSN_NO_SIDE_STREAM") ? st : sc->side;
+  if ((rc = side_ctx(P.sc))) return rc;
+  hipStream_t side = P.opt.no_side_stream ? st : sc->side;
   const int B = d->B, T = d->T, H = d->H, NL = d->L;
   const int64_t G = 4 * (int64_t)H, TB = (int64_t)T * B;
   const size_t Bpad = ((size_t)B + 63) / 64 * 64;
-  const int Cz = chunk_steps(), lag = 2 * Cz;
+  const int Cz = P.opt.chunk, lag = 2 * Cz;
   const int nch = (T + Cz - 1) / Cz;
 
   for (int l = 0; l < NL; ++l) {
@@ -660,10 +734,10 @@ static int backward_il(const csnLstmDesc* d, const WsLayout& w, char* ws, const 
     float* slabs = (float*)(ws + w.tn_scratch);
     int S = 1, r;
     int cs_done = 0, S_cs = 1;
-    if ((r = launch_gemm_tn_slabs(ws + L.dgates, ws + L.h_all, slabs, G, H, TB, CSN_BF16, side, &S, (float*)(ws + w.colsum), &cs_done))) return r;
+    if ((r = launch_gemm_tn_slabs(ws + L.dgates, ws + L.h_all, slabs, G, H, TB, CSN_BF16, side, &S, (float*)(ws + w.colsum), &cs_done, P.opt))) return r;
     S_cs = S;
     if ((r = launch_reduce_slabs_unperm(slabs, G * H, S, H, H, dw_hh[l], side))) return r;
-    if ((r = launch_gemm_tn_slabs(ws + L.dgates, inp, slabs, G, I, TB, CSN_BF16, side, &S, nullptr, nullptr))) return r;
+    if ((r = launch_gemm_tn_slabs(ws + L.dgates, inp, slabs, G, I, TB, CSN_BF16, side, &S, nullptr, nullptr, P.opt))) return r;
     if ((r = launch_reduce_slabs_unperm(slabs, G * I, S, H, I, dw_ih[l], side))) return r;
     // bias gradient = column sums of dgates: partial sums come out of the dW_hh GEMM when its kernel provides them
     if (!cs_done) {
@@ -679,7 +753,7 @@ static int backward_il(const csnLstmDesc* d, const WsLayout& w, char* ws, const 
   std::vector<hipEvent_t> dx_ready((size_t)NL * nch, nullptr);
   const int D = T + lag * (NL - 1);
   int n_launch = 0, n_cells = 0;
-  if ((rc = prof_mark(2, st))) return rc;
+  if ((rc = prof_mark(g_prof, 2, st))) return rc;
   for (int dg = 0; dg < D; ++dg) {
     CellBwdArgs a{};
     a.B = B;
@@ -727,17 +801,17 @@ static int backward_il(const csnLstmDesc* d, const WsLayout& w, char* ws, const 
       }
       if (l > 0) {
         // dx_l[chunk] = dgates_l[chunk] (interleaved K) * W_ih;  Bt = W_ih^T [I, 4H']
-        rc = csn_gemm_nt((const bf16_t*)(ws + L.dgates) + (size_t)t_lo * B * G, ws + L.wiht, nullptr,
+        rc = gemm_nt((const bf16_t*)(ws + L.dgates) + (size_t)t_lo * B * G, ws + L.wiht, nullptr,
                          (float*)(ws + L.dx) + (size_t)t_lo * B * I, (int64_t)(t_hi - t_lo + 1) * B, I, G, CSN_BF16,
-                         CSN_F32, 0, (csnStream_t)side);
+                         CSN_F32, 0, side, P.opt);
         if (rc) return rc;
         hipEvent_t ev;
         if ((rc = next_event(sc, &ev))) return rc;
         CSN_HIP_CHECK(hipEventRecord(ev, side));
         dx_ready[(size_t)l * nch + cr] = ev;
       } else if (last && dx != nullptr) {
-        rc = csn_gemm_nt(ws + L.dgates, ws + L.wiht, nullptr, ws + L.dx, TB, I, G, CSN_BF16, CSN_F32, 0,
-                         (csnStream_t)side);
+        rc = gemm_nt(ws + L.dgates, ws + L.wiht, nullptr, ws + L.dx, TB, I, G, CSN_BF16, CSN_F32, 0,
+                         side, P.opt);
         if (rc) return rc;
         tb_to_bt_kernel<<<grid_for(TB * I), 256, 0, side>>>((const float*)(ws + L.dx), dx, B, T, (int)I);
         CSN_LAUNCH_CHECK();
@@ -745,7 +819,7 @@ static int backward_il(const csnLstmDesc* d, const WsLayout& w, char* ws, const 
       if (last && (rc = weight_grads(l))) return rc;
     }
   }
-  if ((rc = prof_mark(3, st))) return rc;
+  if ((rc = prof_mark(g_prof, 3, st))) return rc;
   g_prof.launches[1] = n_launch;
   g_prof.cells[1] = n_cells;
   g_prof.have[1] = g_prof.on;
@@ -763,15 +837,18 @@ static int backward_il(const csnLstmDesc* d, const WsLayout& w, char* ws, const 
 // the launch was measured too: the event waits between the streams cost ~30 us per launch, most of the gain.)
 // CSN_NO_BESIDE: lag one chunk, GEMM between two launches.
 // The weight / bias gradients follow once the recurrence is complete.
-static int backward_persist(const csnLstmDesc* d, const WsLayout& w, char* ws, const float* dy_last,
+static int backward_persist(Plan& P, char* ws, const float* dy_last,
                             const float* dy_tm, float* const* dw_ih, float* const* dw_hh, float* const* db_ih,
                             float* const* db_hh, float* dx, hipStream_t st) {
+  const csnLstmDesc* d = &P.d;
+  const WsLayout& w = P.w;
+  Prof& g_prof = P.prof;
   const int B = d->B, T = d->T, H = d->H, NL = d->L;
   const int64_t G = 4 * (int64_t)H, TB = (int64_t)T * B;
   const int Bpad = (B + 63) / 64 * 64, MT = Bpad / 64;
-  const int Cz = chunk_steps();
+  const int Cz = P.opt.chunk;
   const int nch = (T + Cz - 1) / Cz;
-  const bool beside = NL > 1 && NL <= 4 && bwd_persist_slices(H) <= 28 && G % 64 == 0 && getenv("CSN_NO_BESIDE") == nullptr;
+  const bool beside = NL > 1 && NL <= 4 && bwd_persist_slices(H) <= 28 && G % 64 == 0 && !P.opt.no_beside;
   const int lag = beside ? 2 : 1;
   const int ndiag = nch + lag * (NL - 1);
   int rc;
@@ -780,7 +857,7 @@ static int backward_persist(const csnLstmDesc* d, const WsLayout& w, char* ws, c
     CSN_HIP_CHECK(hipMemsetAsync(ws + L.dc_carry, 0, (size_t)B * H * 4, st));
     CSN_HIP_CHECK(hipMemsetAsync(ws + L.bflags, 0, (size_t)T * MT * kPersistFlagLine * 4, st));
   }
-  const bool try_local = getenv("CSN_NO_XCD_LOCAL") == nullptr;
+  const bool try_local = !P.opt.no_xcd_local;
   if (try_local) CSN_HIP_CHECK(hipMemsetAsync(ws + w.agree, 0, (size_t)ndiag * 8 * sizeof(unsigned long long), st));
   CSN_HIP_CHECK(hipMemsetAsync(ws + w.zeros_bh, 0, (size_t)B * H * 4, st));
 
@@ -789,11 +866,11 @@ static int backward_persist(const csnLstmDesc* d, const WsLayout& w, char* ws, c
   a.B = B; a.H = H; a.T = T; a.Bpad = Bpad; a.MT = MT;
   a.xcd_groups = 1;
   a.grid_slices = 32;
-  a.rotate = getenv("CSN_NO_ROTATE") == nullptr;
+  a.rotate = !P.opt.no_rotate;
   int n_launch = 0;
   BesideGemm pending[3];           // GEMMs of the chunks finished by the previous launch
   int npending = 0;
-  if ((rc = prof_mark(2, st))) return rc;
+  if ((rc = prof_mark(g_prof, 2, st))) return rc;
   for (int dg = 0; dg < ndiag; ++dg) {
     int lay[4], chk[4], ns = 0;
     for (int l = NL - 1; l >= 0; --l) {
@@ -827,9 +904,9 @@ static int backward_persist(const csnLstmDesc* d, const WsLayout& w, char* ws, c
     for (int i = 0; i < npending; ++i) a.gemm[i] = pending[i];
     npending = 0;
     a.agree = try_local ? (unsigned long long*)(ws + w.agree) + (size_t)dg * 8 : nullptr;
-    if ((rc = prof_pair(1, false, st))) return rc;
+    if ((rc = prof_pair(g_prof, 1, false, st))) return rc;
     if ((rc = launch_bwd_persist(a, st))) return rc;
-    if ((rc = prof_pair(1, true, st))) return rc;
+    if ((rc = prof_pair(g_prof, 1, true, st))) return rc;
     ++n_launch;
     for (int i = 0; i < ns; ++i) {
       const int l = lay[i];
@@ -843,19 +920,19 @@ static int backward_persist(const csnLstmDesc* d, const WsLayout& w, char* ws, c
       if (beside) {
         pending[npending++] = BesideGemm{Ag, (const bf16_t*)(ws + L.wiht), Cg, (int)Mg, H, (int)G};
       } else {
-        if ((rc = csn_gemm_nt(Ag, ws + L.wiht, nullptr, Cg, Mg, H, G, CSN_BF16, CSN_F32, 0, (csnStream_t)st))) return rc;
+        if ((rc = gemm_nt(Ag, ws + L.wiht, nullptr, Cg, Mg, H, G, CSN_BF16, CSN_F32, 0, st, P.opt))) return rc;
       }
     }
   }
-  if ((rc = prof_mark(3, st))) return rc;
+  if ((rc = prof_mark(g_prof, 3, st))) return rc;
   g_prof.launches[1] = n_launch;
   g_prof.cells[1] = T * NL;
   g_prof.have[1] = g_prof.on;
 
   if (dx != nullptr) {
     const LayerWs& L = w.layer[0];
-    if ((rc = csn_gemm_nt(ws + L.dgates, ws + L.wiht, nullptr, ws + L.dx, TB, d->I, G, CSN_BF16, CSN_F32, 0,
-                          (csnStream_t)st)))
+    if ((rc = gemm_nt(ws + L.dgates, ws + L.wiht, nullptr, ws + L.dx, TB, d->I, G, CSN_BF16, CSN_F32, 0,
+                          st, P.opt)))
       return rc;
     tb_to_bt_kernel<<<grid_for(TB * d->I), 256, 0, st>>>((const float*)(ws + L.dx), dx, B, T, d->I);
     CSN_LAUNCH_CHECK();
@@ -868,10 +945,10 @@ static int backward_persist(const csnLstmDesc* d, const WsLayout& w, char* ws, c
     float* slabs = (float*)(ws + w.tn_scratch);
     int S = 1;
     int cs_done = 0, S_cs = 1;
-    if ((rc = launch_gemm_tn_slabs(ws + L.dgates, ws + L.h_all, slabs, G, H, TB, CSN_BF16, st, &S, (float*)(ws + w.colsum), &cs_done))) return rc;
+    if ((rc = launch_gemm_tn_slabs(ws + L.dgates, ws + L.h_all, slabs, G, H, TB, CSN_BF16, st, &S, (float*)(ws + w.colsum), &cs_done, P.opt))) return rc;
     S_cs = S;
     if ((rc = launch_reduce_slabs_unperm(slabs, G * H, S, H, H, dw_hh[l], st))) return rc;
-    if ((rc = launch_gemm_tn_slabs(ws + L.dgates, inp, slabs, G, I, TB, CSN_BF16, st, &S, nullptr, nullptr))) return rc;
+    if ((rc = launch_gemm_tn_slabs(ws + L.dgates, inp, slabs, G, I, TB, CSN_BF16, st, &S, nullptr, nullptr, P.opt))) return rc;
     if ((rc = launch_reduce_slabs_unperm(slabs, G * I, S, H, I, dw_ih[l], st))) return rc;
     // bias gradient = column sums of dgates: partial sums come out of the dW_hh GEMM when its kernel provides them
     if (!cs_done) {
@@ -886,27 +963,34 @@ static int backward_persist(const csnLstmDesc* d, const WsLayout& w, char* ws, c
 }
 
 // =============================================================================================
-extern "C" int csn_lstm_forward(const csnLstmDesc* d, const float* x, int64_t x_stride_b, int64_t x_stride_t,
+extern "C" int csn_lstm_forward(csnLstmPlan* Pp, const float* x, int64_t x_stride_b, int64_t x_stride_t,
                                 const float* const* w_ih, const float* const* w_hh, const float* const* b_ih,
-                                const float* const* b_hh, void* workspace, int training, float* y_last, float* y_all,
+                                const float* const* b_hh, void* workspace, float* y_last, float* y_all,
                                 csnStream_t stream) {
-  if (int rc = check_desc("csn_lstm_forward", d)) return rc;
+  CSN_REQUIRE(Pp != nullptr, "csn_lstm_forward: null plan");
+  Plan& P = *Pp;
+  const csnLstmDesc* d = &P.d;
   CSN_REQUIRE(x && w_ih && w_hh && b_ih && b_hh && workspace, "csn_lstm_forward: null pointer");
   CSN_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 255) == 0, "csn_lstm_forward: workspace must be 256-B aligned");
   CSN_REQUIRE(y_last || y_all, "csn_lstm_forward: no output requested");
   for (int l = 0; l < d->L; ++l)
     CSN_REQUIRE(w_ih[l] && w_hh[l] && b_ih[l] && b_hh[l], "csn_lstm_forward: null parameter pointer, layer %d", l);
+  int dev = -1;
+  CSN_HIP_CHECK(hipGetDevice(&dev));
+  CSN_REQUIRE(dev == P.device, "csn_lstm_forward: plan was created on device %d, current device is %d", P.device, dev);
   hipStream_t st = as_stream(stream);
-  const WsLayout w = make_layout(*d, training);
+  const WsLayout& w = P.w;
+  const int training = P.training;
   char* ws = (char*)workspace;
   const int B = d->B, T = d->T, H = d->H, dt = d->dtype;
   const size_t es = dtype_size(dt);
   int rc;
-  CSN_HIP_CHECK(hipMemsetAsync(ws + w.status, 0, 256, st));
+  // (the status word is NOT cleared here: it stays raised from the first timed-out hand-off until
+  // csn_lstm_status_clear, so a check at the end of an epoch / a timed region covers every step in it)
   if (w.il)
-    rc = forward_il(d, w, ws, x, x_stride_b, x_stride_t, w_ih, w_hh, b_ih, b_hh, training, stream);
+    rc = forward_il(P, ws, x, x_stride_b, x_stride_t, w_ih, w_hh, b_ih, b_hh, training, stream);
   else
-    rc = forward_v1(d, w, ws, x, x_stride_b, x_stride_t, w_ih, w_hh, b_ih, b_hh, training, stream);
+    rc = forward_v1(P, ws, x, x_stride_b, x_stride_t, w_ih, w_hh, b_ih, b_hh, training, stream);
   if (rc) return rc;
   const LayerWs& top = w.layer[d->L - 1];
   if (y_last)
@@ -922,16 +1006,22 @@ extern "C" int csn_lstm_forward(const csnLstmDesc* d, const float* x, int64_t x_
   return CSN_OK;
 }
 
-extern "C" int csn_lstm_backward(const csnLstmDesc* d, const float* dy_last, const float* dy_all, void* workspace,
+extern "C" int csn_lstm_backward(csnLstmPlan* Pp, const float* dy_last, const float* dy_all, void* workspace,
                                  float* const* dw_ih, float* const* dw_hh, float* const* db_ih, float* const* db_hh,
                                  float* dx, csnStream_t stream) {
-  if (int rc = check_desc("csn_lstm_backward", d)) return rc;
+  CSN_REQUIRE(Pp != nullptr, "csn_lstm_backward: null plan");
+  Plan& P = *Pp;
+  const csnLstmDesc* d = &P.d;
+  CSN_REQUIRE(P.training, "csn_lstm_backward: the plan was created with training = 0");
   CSN_REQUIRE(workspace && dw_ih && dw_hh && db_ih && db_hh, "csn_lstm_backward: null pointer");
   CSN_REQUIRE(dy_last || dy_all, "csn_lstm_backward: no incoming gradient");
   for (int l = 0; l < d->L; ++l)
     CSN_REQUIRE(dw_ih[l] && dw_hh[l] && db_ih[l] && db_hh[l], "csn_lstm_backward: null gradient pointer, layer %d", l);
+  int dev = -1;
+  CSN_HIP_CHECK(hipGetDevice(&dev));
+  CSN_REQUIRE(dev == P.device, "csn_lstm_backward: plan was created on device %d, current device is %d", P.device, dev);
   hipStream_t st = as_stream(stream);
-  const WsLayout w = make_layout(*d, 1);
+  const WsLayout& w = P.w;
   char* ws = (char*)workspace;
   const int B = d->B, T = d->T, H = d->H;
   const int64_t TB = (int64_t)T * B;
@@ -948,6 +1038,6 @@ extern "C" int csn_lstm_backward(const csnLstmDesc* d, const float* dy_last, con
     }
     dy_tm = buf;
   }
-  if (w.il) return backward_il(d, w, ws, dy_last, dy_tm, dw_ih, dw_hh, db_ih, db_hh, dx, stream);
-  return backward_v1(d, w, ws, dy_last, dy_tm, dw_ih, dw_hh, db_ih, db_hh, dx, stream);
+  if (w.il) return backward_il(P, ws, dy_last, dy_tm, dw_ih, dw_hh, db_ih, db_hh, dx, stream);
+  return backward_v1(P, ws, dy_last, dy_tm, dw_ih, dw_hh, db_ih, db_hh, dx, stream);
 }

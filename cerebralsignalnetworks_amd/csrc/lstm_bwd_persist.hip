@@ -346,8 +346,8 @@ __global__ void __launch_bounds__(256) lstm_bwd_persist_kernel(PersistBwdArgs a)
     if (pok[ps]) *reinterpret_cast<float4*>(S.dc_carry + (size_t)prow[ps] * H + puq[ps]) = dcn[ps];
 }
 
-bool bwd_persist_supported(int B, int H, int dtype) {
-  if (dtype != CSN_BF16 || getenv("CSN_NO_PERSIST") != nullptr || getenv("CSN_NO_PERSIST_BWD") != nullptr) return false;
+bool bwd_persist_supported(int B, int H, int dtype, const Options& opt) {
+  if (dtype != CSN_BF16 || opt.no_persist || opt.no_persist_bwd) return false;
   return H == 128 || H == 256 || H == 384 || H == 512 || H == 768;
 }
 int bwd_persist_slices(int H) { return H / 32; }
@@ -355,12 +355,7 @@ int bwd_persist_slices(int H) { return H / 32; }
 template <int NUT, int KS>
 static int launch_bwd_persist_t(const PersistBwdArgs& a, hipStream_t st) {
   size_t lds = (size_t)4 * 4 * NUT * 65 * sizeof(float4);
-  static bool attr_done = false;
-  if (!attr_done) {
-    CSN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_bwd_persist_kernel<NUT, KS>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBesideLdsBytes));
-    attr_done = true;
-  }
+  if (int rc = ensure_dyn_lds<&lstm_bwd_persist_kernel<NUT, KS>>((int)kBesideLdsBytes)) return rc;
   const unsigned nslices = (unsigned)(a.H / (16 * NUT));
   PersistBwdArgs b = a;
   if (b.xcd_groups) {

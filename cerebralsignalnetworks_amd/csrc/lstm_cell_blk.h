@@ -68,7 +68,7 @@ struct PersistFwdArgs {
   unsigned* error_flag;    // sticky: a bounded spin gave up
   int B, H, T, Bpad, MT;
 };
-bool fwd_persist_supported(int B, int H, int dtype);
+bool fwd_persist_supported(int B, int H, int dtype, const Options& opt);
 int fwd_persist_slices(int H);   // workgroups per hand-off group
 int launch_fwd_persist(const PersistFwdArgs& a, hipStream_t st);
 
@@ -107,12 +107,12 @@ struct PersistBwdArgs {
   unsigned* error_flag;
   int B, H, T, Bpad, MT;
 };
-bool bwd_persist_supported(int B, int H, int dtype);
+bool bwd_persist_supported(int B, int H, int dtype, const Options& opt);
 int bwd_persist_slices(int H);
 int launch_bwd_persist(const PersistBwdArgs& a, hipStream_t st);
 
-bool cell_blk_supported(int H, int dtype);
-int launch_cell_fwd_il(const CellFwdArgs& a, int nprob, hipStream_t st);
+bool cell_blk_supported(int H, int dtype, const Options& opt);
+int launch_cell_fwd_il(const CellFwdArgs& a, int nprob, hipStream_t st, int max_nk);
 int launch_cell_bwd_il(const CellBwdArgs& a, int nprob, hipStream_t st);
 int launch_blockify_x(const float* x, int64_t xsb, int64_t xst, int B, int T, int I, void* dst, hipStream_t st);
 int launch_blockify(const float* src, int64_t ld_r, int64_t ld_k, int64_t R, int64_t K, int perm_r, int perm_k,

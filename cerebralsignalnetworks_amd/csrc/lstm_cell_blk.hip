@@ -451,30 +451,24 @@ static int pick_nk(int steps, int max_nk) {
   return 1;
 }
 
-bool cell_blk_supported(int H, int dtype) {
-  return dtype == CSN_BF16 && H % 128 == 0 && getenv("CSN_CELL_V1") == nullptr;
+bool cell_blk_supported(int H, int dtype, const Options& opt) {
+  return dtype == CSN_BF16 && H % 128 == 0 && !opt.cell_v1;
 }
 
 template <int NQ, int NK>
 static int launch_fwd_t(const CellFwdArgs& a, int nprob, hipStream_t st) {
   const size_t lds = (size_t)4 * 4 * NQ * 65 * sizeof(float4);
-  static bool attr_done = false;
-  if (!attr_done) {
-    CSN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_cell_fwd_il_kernel<NQ, NK>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_done = true;
-  }
+  if (int rc = ensure_dyn_lds<&lstm_cell_fwd_il_kernel<NQ, NK>>((int)lds)) return rc;
   dim3 grid((unsigned)(a.H / (4 * NQ)), (unsigned)((a.B + 63) / 64), (unsigned)nprob);
   lstm_cell_fwd_il_kernel<NQ, NK><<<grid, 256, lds, st>>>(a);
   CSN_LAUNCH_CHECK();
   return CSN_OK;
 }
 
-int launch_cell_fwd_il(const CellFwdArgs& a, int nprob, hipStream_t st) {
+int launch_cell_fwd_il(const CellFwdArgs& a, int nprob, hipStream_t st, int max_nk) {
   const int H = a.H;
   const int steps = H / 128;                       // k-steps per wave
-  const char* env_nk = getenv("CSN_FWD_NK");
-  const int nk = pick_nk(steps, env_nk ? atoi(env_nk) : 1);
+  const int nk = pick_nk(steps, max_nk);
   const int nq = (H % 24 == 0) ? 6 : ((H % 32 == 0) ? 8 : 4);
 #define CSN_CASE(NQ, NK) if (nq == NQ && nk == NK) return launch_fwd_t<NQ, NK>(a, nprob, st)
   CSN_CASE(6, 3); CSN_CASE(6, 2); CSN_CASE(6, 1);

@@ -396,19 +396,14 @@ __global__ void __launch_bounds__(256) lstm_fwd_persist_kernel(PersistFwdArgs a)
 
 // The weight-stationary kernels place one workgroup per CU and need all of a launch co-resident: they are used
 // only on a full MI355X (256 CUs; smaller partitions take the per-timestep launches).
-static bool device_has_256_cus() {
-  static int cached[16] = {0};               // 0 unknown, 1 yes, -1 no
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return false;
-  if (cached[dev] == 0) {
-    int cus = 0;
-    cached[dev] = (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus >= 256) ? 1 : -1;
-  }
-  return cached[dev] == 1;
+static bool device_has_256_cus() {       // asked when a layout is made (plan creation), not per launch
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return false;
+  return hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus >= 256;
 }
 
-bool fwd_persist_supported(int B, int H, int dtype) {
-  if (dtype != CSN_BF16 || H % 128 != 0 || getenv("CSN_NO_PERSIST") != nullptr) return false;
+bool fwd_persist_supported(int B, int H, int dtype, const Options& opt) {
+  if (dtype != CSN_BF16 || H % 128 != 0 || opt.no_persist) return false;
   if (!device_has_256_cus()) return false;
   const int nq = (H % 24 == 0) ? 6 : 8, ks = H / 128;
   const bool shape = (nq == 6 && (ks == 6 || ks == 3)) || (nq == 8 && (ks == 4 || ks == 2 || ks == 1));
@@ -422,12 +417,7 @@ int fwd_persist_slices(int H) { return H / (4 * ((H % 24 == 0) ? 6 : 8)); }
 template <int NQ, int KS>
 static int launch_persist_t(const PersistFwdArgs& a, hipStream_t st) {
   const size_t lds = (size_t)(4 * 4 * NQ * 65 + 4 * NQ) * sizeof(float4);
-  static bool attr_done = false;
-  if (!attr_done) {
-    CSN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_fwd_persist_kernel<NQ, KS>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_done = true;
-  }
+  if (int rc = ensure_dyn_lds<&lstm_fwd_persist_kernel<NQ, KS>>((int)lds)) return rc;
   const unsigned nslices = (unsigned)(a.H / (4 * NQ));
   const unsigned grid = a.xcd_groups ? 8u * nslices : nslices * (unsigned)(a.MT * a.nslots);
   lstm_fwd_persist_kernel<NQ, KS><<<dim3(grid), 256, lds, st>>>(a);

@@ -15,6 +15,23 @@ import torch.nn as nn
 from . import cabi
 
 
+class _Lease:
+    """Holds a plan (= its workspace) for one autograd node.  Released by the node's backward -- or, when the
+    graph is dropped without a backward (a skipped step, a validation pass without no_grad, an exception between
+    forward and backward), when the node itself is collected, so such a forward never pins a workspace for good."""
+
+    def __init__(self, plan):
+        self.plan = plan
+        plan.busy = True
+
+    def release(self):
+        if self.plan is not None:
+            self.plan.busy = False
+            self.plan = None
+
+    __del__ = release
+
+
 class _LstmFunction(torch.autograd.Function):
     """Stacked LSTM over libcsn_hip.  A training forward keeps its state in a workspace that stays
     checked out until the matching backward has run, so several forwards (e.g. the multi-crop views of
@@ -25,23 +42,26 @@ class _LstmFunction(torch.autograd.Function):
         w_ih, w_hh, b_ih, b_hh = params[0:L], params[L:2 * L], params[2 * L:3 * L], params[3 * L:4 * L]
         plan = owner._checkout(x.shape[0], x.shape[1], x.device, training)
         y_last, y_all = plan.forward(x, w_ih, w_hh, b_ih, b_hh, want_all=want_all)
-        ctx.plan, ctx.owner, ctx.L, ctx.want_all = plan, owner, L, want_all
+        ctx.lease, ctx.L, ctx.want_all = _Lease(plan), L, want_all
         ctx.need_dx = x.requires_grad
         ctx.x_shape = x.shape
         ctx.param_like = params
         if not training:
-            owner._release(plan)
+            ctx.lease.release()
         if want_all:
             return y_last, y_all
         return y_last, y_last.new_empty(0)
 
     @staticmethod
     def backward(ctx, dy_last, dy_all):
-        L, plan = ctx.L, ctx.plan
+        L, plan = ctx.L, ctx.lease.plan
+        if plan is None:
+            raise RuntimeError("HipLSTM: second backward through one forward -- its workspace was handed back after the "
+                               "first (retain_graph / double backward are not supported)")
         grads = [[torch.empty_like(p) for p in ctx.param_like[g * L:(g + 1) * L]] for g in range(4)]
         dx = torch.empty(ctx.x_shape, dtype=torch.float32, device=dy_last.device) if ctx.need_dx else None
         plan.backward(dy_last, dy_all if ctx.want_all else None, grads, dx=dx)
-        ctx.owner._release(plan)
+        ctx.lease.release()
         flat = [g for group in grads for g in group]
         return (dx, None, None, None, None, *flat)
 
@@ -69,7 +89,6 @@ class HipLSTM(nn.Module):
         pool = self._plans.setdefault(key, [])
         for plan in pool:
             if not plan.busy:
-                plan.busy = True
                 return plan
         idle = [(k, pl) for k, lst in self._plans.items() for pl in lst if not pl.busy and k != key]
         while len(idle) >= self.MAX_IDLE_PLANS:
@@ -77,13 +96,8 @@ class HipLSTM(nn.Module):
             self._plans[k].remove(pl)
         plan = cabi.LstmPlan(B, T, self.input_size, self.hidden_size, self.num_layers, self.compute_dtype, device,
                              training=training)
-        plan.busy = True
         pool.append(plan)
         return plan
-
-    @staticmethod
-    def _release(plan):
-        plan.busy = False
 
     def all_plans(self):
         return [pl for lst in self._plans.values() for pl in lst]

@@ -77,6 +77,22 @@ def shard_indices(n, epoch, seed, rank, world, shuffle=True, device="cpu"):
     return idx[rank:total:world].to(device)
 
 
+def check_device_status(model):
+    """Blocking: raises if an in-kernel hand-off of a weight-stationary LSTM kernel timed out in ANY forward /
+    backward of ``model`` since the last check (the status word is sticky; results from that step on are invalid).
+    Call it at epoch ends / after a timed region / after an evaluation pass, not per step.  Cleared once reported."""
+    from .lstm_model import HipLSTM
+    torch.cuda.synchronize()
+    bad = False
+    for mod in model.modules():
+        if isinstance(mod, HipLSTM):
+            for plan in mod.all_plans():
+                bad |= plan.status(clear=True) != 0
+    if bad:
+        raise RuntimeError("libcsn_hip: a bounded in-kernel wait of the LSTM recurrence timed out "
+                           "(is another process using this GPU's CUs?); results are invalid")
+
+
 class DistillTrainer:
     def __init__(self, model, sos, ddof=0, loss="cosine", lr=1e-3, optimizer="rmsprop", nepochs=100,
                  kd_params=None, preprocess=True):
@@ -144,16 +160,7 @@ class DistillTrainer:
         return loss.detach()
 
     def check_device_status(self):
-        """Blocking: raises if an in-kernel hand-off of a weight-stationary LSTM kernel ever timed out (the
-        results of that step are then invalid).  Call it at epoch ends / after a timed region, not per step."""
-        from .lstm_model import HipLSTM
-        torch.cuda.synchronize()
-        for mod in self.model.modules():
-            if isinstance(mod, HipLSTM):
-                for plan in mod.all_plans():
-                    if plan.status() != 0:
-                        raise RuntimeError("libcsn_hip: a bounded in-kernel wait of the LSTM recurrence timed out "
-                                           "(is another process using this GPU's CUs?); results are invalid")
+        check_device_status(self.model)
 
     @torch.no_grad()
     def embed_all(self, eeg_all, batch):

@@ -36,7 +36,7 @@ enum csnStatus {
 enum csnDtype { CSN_F32 = 0, CSN_BF16 = 1 };
 
 /* ABI version of this header; bumped on any signature change. */
-#define CSN_ABI_VERSION 1
+#define CSN_ABI_VERSION 2
 int csn_abi_version(void);
 /* Thread-local message for the last non-zero status returned on this thread. */
 const char* csn_last_error(void);
@@ -84,44 +84,65 @@ typedef struct csnLstmDesc {
   int32_t dtype;  /* CSN_BF16: bf16 MFMA operands, f32 accumulate/state; CSN_F32: exact f32 MFMA */
 } csnLstmDesc;
 
-/* Bytes of device scratch the forward (+ backward if training) needs; 256-B aligned base. */
+/* A PLAN holds everything host-side that a stacked-LSTM problem of one shape needs: the workspace layout, the
+ * diagnostic switches (environment, read once here), library-owned side streams, an event pool, profiling events.
+ * The library keeps NO mutable global state: plans are independent of each other, so different host threads /
+ * streams / devices use different plans freely.  One plan must not be used from two threads at once, and it is
+ * bound to the device that was current when it was created.  training != 0: the forward keeps what
+ * csn_lstm_backward needs.  (There is nothing like this in the reference: torch's nn.LSTM hides the same state in
+ * cuDNN/MIOpen descriptors and the autograd graph.) */
+typedef struct csnLstmPlan csnLstmPlan;
+int csn_lstm_plan_create(const csnLstmDesc* d, int training, csnLstmPlan** out);
+void csn_lstm_plan_destroy(csnLstmPlan* plan);
+/* Bytes of device scratch ("workspace") a forward (+ backward) of this plan needs; 256-B aligned base.  The
+ * caller owns it; one plan may be used with several workspaces (e.g. several forwards awaiting their backward). */
+size_t csn_lstm_plan_workspace_bytes(const csnLstmPlan* plan);
+/* Which kernels the plan runs: 0 generic per-step cells (exact f32 / odd shapes), 1 per-diagonal bf16 launches,
+ * 2 weight-stationary forward, 3 weight-stationary forward and backward. */
+int csn_lstm_plan_path(const csnLstmPlan* plan);
+/* Same number without a plan (what csn_lstm_plan_workspace_bytes would return for a plan created now). */
 size_t csn_lstm_workspace_bytes(const csnLstmDesc* d, int training);
 
 /* x: element (b,t,i) at x[b*x_stride_b + t*x_stride_t + i] (float32).
  * w_ih/w_hh/b_ih/b_hh: [host] arrays of L device pointers to float32 parameters
  *   weight_ih_l{k}[4H,I_k], weight_hh_l{k}[4H,H], bias_ih_l{k}[4H], bias_hh_l{k}[4H].
  * y_last: [B,H] float32 = output of the top layer at t = T-1.
- * y_all : optional (may be NULL) [B,T,H] float32, every step of the top layer.
- * The workspace keeps what csn_lstm_backward needs when training != 0. */
-int csn_lstm_forward(const csnLstmDesc* d,
+ * y_all : optional (may be NULL) [B,T,H] float32, every step of the top layer. */
+int csn_lstm_forward(csnLstmPlan* plan,
                      const float* x, int64_t x_stride_b, int64_t x_stride_t,
                      const float* const* w_ih, const float* const* w_hh,
                      const float* const* b_ih, const float* const* b_hh,
-                     void* workspace, int training,
-                     float* y_last, float* y_all, csnStream_t stream);
+                     void* workspace, float* y_last, float* y_all, csnStream_t stream);
 
 /* dy_last: [B,H] float32 gradient w.r.t. y_last (may be NULL).
  * dy_all : optional [B,T,H] float32 gradient w.r.t. y_all (may be NULL).
  * dw_ih/dw_hh/db_ih/db_hh: [host] arrays of L device pointers, float32, OVERWRITTEN.
  * dx: optional [B,T,I] float32 (dense), gradient w.r.t. x (may be NULL). */
-int csn_lstm_backward(const csnLstmDesc* d,
+int csn_lstm_backward(csnLstmPlan* plan,
                       const float* dy_last, const float* dy_all,
                       void* workspace,
                       float* const* dw_ih, float* const* dw_hh,
                       float* const* db_ih, float* const* db_hh,
                       float* dx, csnStream_t stream);
 
-/* Blocking read (device -> host) of the workspace's status word after a forward: 0 = ok; non-zero =
- * a bounded in-kernel wait of the weight-stationary forward gave up (results are invalid). */
-int csn_lstm_read_status(const csnLstmDesc* d, const void* workspace, int training, int* status);
+/* The workspace's status word: 0 = ok; non-zero = a bounded in-kernel wait of a weight-stationary kernel gave
+ * up at some point since the word was last cleared (the results of that forward / backward and of every later
+ * one are invalid).  It is STICKY: no forward or backward clears it.  csn_lstm_status_clear zeroes it (enqueued on
+ * `stream`): call it once after allocating a workspace and after a reported error has been handled.
+ * csn_lstm_status_read is a blocking device -> host read.  csn_lstm_status_raise is fault injection for tests of
+ * the error path: it leaves the word exactly as a timed-out wait does (every later bounded wait then returns at
+ * once, so nothing hangs; results are garbage by construction). */
+int csn_lstm_status_clear(const csnLstmPlan* plan, void* workspace, csnStream_t stream);
+int csn_lstm_status_read(const csnLstmPlan* plan, const void* workspace, int* status);
+int csn_lstm_status_raise(const csnLstmPlan* plan, void* workspace, csnStream_t stream);
 
-/* Optional timing of the recurrence kernels with HIP events recorded on the caller's stream in the most
+/* Optional timing of the plan's recurrence kernels with HIP events recorded on the caller's stream in its most
  * recent forward / backward: around every weight-stationary launch (the time reported is the sum over the
  * launches, the GEMMs between them excluded), or around the whole launch loop of the per-timestep cell
  * kernels.  csn_lstm_profile_read synchronises on those events; *_launches = recurrence launches;
  * *_cells = cell problems (layer-steps) those launches advanced. */
-int csn_lstm_profile_enable(int on);
-int csn_lstm_profile_read(double* fwd_ms, int* fwd_launches, int* fwd_cells,
+int csn_lstm_profile_enable(csnLstmPlan* plan, int on);
+int csn_lstm_profile_read(csnLstmPlan* plan, double* fwd_ms, int* fwd_launches, int* fwd_cells,
                           double* bwd_ms, int* bwd_launches, int* bwd_cells);
 
 /* ------------------------------------------------------------------------------------

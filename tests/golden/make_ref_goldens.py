@@ -428,25 +428,13 @@ def ref_preproc():
 # ------------------------------------------------------------------------------------------------
 # retrieval acceptance set (north star: bf16 top-1 within +-0.5 % of the CPU reference)
 # ------------------------------------------------------------------------------------------------
-def clustered_eeg(n, n_classes=40, C=128, T=500, seed=101, snr=0.2):
-    """Seeded class-clustered raw EEG [n, C, T] f32 + labels: class template (low-pass noise) * snr + N(0,1)."""
-    rng = np.random.default_rng(seed)
-    labels = rng.integers(0, n_classes, n)
-    tpl = rng.standard_normal((n_classes, C, T))
-    k = np.hanning(15)
-    k /= k.sum()
-    tpl = np.apply_along_axis(lambda v: np.convolve(v, k, mode="same"), -1, tpl)
-    tpl /= tpl.std(axis=-1, keepdims=True)
-    x = snr * tpl[labels] + rng.standard_normal((n, C, T))
-    return x.astype(np.float32), labels
-
-
 def ref_retrieval(n_gallery=2048, n_query=512):
     """The reference CPU path (scipy sosfilt + z-score -> the reference's LSTMModel, torch f32, eval) embeds a seeded
     clustered set at cfg2; stored: its top-5 neighbour lists / top-1 (exact L2 in f64), labels, a sample of the
-    embeddings.  Inputs are regenerated from the seed at test time (clustered_eeg is restated in the test helper)."""
+    embeddings.  Inputs are regenerated from the seed at test time (oracle.eeg_filter.clustered_eeg)."""
     from oracle.lstm import init_params
     from oracle import cpu_path, eeg_filter, retrieval
+    from oracle.eeg_filter import clustered_eeg
     C, T, H, L, D = 128, 500, 768, 2, 384
     ns = lift("LSTMDistillRetreival.py", ["LSTMModel"])
     params = init_params(C, H, L, D, None, seed=43)
