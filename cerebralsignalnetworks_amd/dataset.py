@@ -29,6 +29,21 @@ def synthetic_eeg(n, channels=128, samples=500, fs=1000.0, freq=40.0, amp=0.5, s
     return torch.randn(n, channels, samples, generator=g) + amp * torch.sin(2 * np.pi * freq * t)
 
 
+def clustered_eeg(n, n_classes=40, C=128, T=500, seed=101, snr=0.2):
+    """Seeded class-clustered raw EEG [n, C, T] f32 + labels: class template (low-pass noise) * snr + N(0,1).
+    The input set of the retrieval acceptance check (bench.py, tests/test_gpu_fullsize.py; the CPU reference's
+    neighbour lists for it are the fixture tests/golden/ref_retrieval_cfg2.npz)."""
+    rng = np.random.default_rng(seed)
+    labels = rng.integers(0, n_classes, n)
+    tpl = rng.standard_normal((n_classes, C, T))
+    k = np.hanning(15)
+    k /= k.sum()
+    tpl = np.apply_along_axis(lambda v: np.convolve(v, k, mode="same"), -1, tpl)
+    tpl /= tpl.std(axis=-1, keepdims=True)
+    x = snr * tpl[labels] + rng.standard_normal((n, C, T))
+    return x.astype(np.float32), labels
+
+
 class EEGDataset(Dataset):
     def __init__(self, eeg_signals_path=None, eeg_splits_path=None, subset='train', subject=1, exclude_subjects=(),
                  filter_channels=(), time_low=20, time_high=480, model_type="cnn",

@@ -178,20 +178,6 @@ def synthetic_eeg(n, channels=128, samples=500, fs=1000.0, freq=40.0, amp=0.5, s
     return x.astype(np.float32)
 
 
-def clustered_eeg(n, n_classes=40, C=128, T=500, seed=101, snr=0.2):
-    """Seeded class-clustered raw EEG [n, C, T] f32 + labels: class template (low-pass noise) * snr + N(0,1).
-    The input set of the retrieval acceptance test (tests/golden/ref_retrieval_cfg2.npz was made from it)."""
-    rng = np.random.default_rng(seed)
-    labels = rng.integers(0, n_classes, n)
-    tpl = rng.standard_normal((n_classes, C, T))
-    k = np.hanning(15)
-    k /= k.sum()
-    tpl = np.apply_along_axis(lambda v: np.convolve(v, k, mode="same"), -1, tpl)
-    tpl /= tpl.std(axis=-1, keepdims=True)
-    x = snr * tpl[labels] + rng.standard_normal((n, C, T))
-    return x.astype(np.float32), labels
-
-
 def classwise_channel_norm(eeg_nct, class_ids, time_low=0, compat_stale_index=False, stored_float32=False):
     """Class-wise, channel-wise normalisation of a dataset, restating
     /root/reference/utils/PerilsEEGDataset.py:464-507 (``transformEEGDataToChannelWiseNorm``).

@@ -17,6 +17,7 @@ runs them on seeded inputs.  Executed definitions (file:line):
   utils/PerilsEEGDataset.py:454-461,464-507,541-623     normlizeEEG, transformEEGDataToChannelWiseNorm, __getitem__
   utils/EEGDataset.py:539-591                           __getitem__ (Spampinato dataset-level (x - means) / stddevs)
   utils/Utilities.py:411-428                            Utilities.remove_noise (zero-phase band-pass)
+  utils/utils.py:594-630 (imported)                     MultiCropWrapper, cosine_scheduler, trunc_normal_
 
 Not executable here, therefore still restated only: ``evaluate`` (faiss), ``extract_features`` /
 ``transformEEGDataLSTMByList`` (hard-coded ``.cuda()``).
@@ -425,16 +426,72 @@ def ref_preproc():
     _save("ref_preproc.npz", out)
 
 
+def ref_dino_step():
+    """One optimisation step's loss / gradients of the DINO self-distillation trainer (LstmDistillation.py:518-596):
+    the reference's MultiCropWrapper (utils/utils.py:594-630), DINOHead and DINOLoss executed around a backbone.
+    The backbone class itself (``models.lstm.Model``) is absent from the reference tree: a torch ``nn.LSTM`` ->
+    last step module with the call-site contract stands in for it here (third-party call; the product's HIP LSTM is
+    what the GPU test puts in its place)."""
+    _ensure_pg()
+    import importlib.util
+    from oracle.lstm import init_params
+    sys.path.insert(0, REF)
+    spec = importlib.util.spec_from_file_location("ref_utils_utils", os.path.join(REF, "utils", "utils.py"))
+    ru = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ru)
+    dn = lift("LstmDistillation.py", ["DINOHead", "DINOLoss"], base_namespace(trunc_normal_=ru.trunc_normal_, utils=ru))
+    B, C, H, L, OUT = 4, 16, 32, 2, 24
+
+    class Backbone(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.lstm = nn.LSTM(C, H, num_layers=L, batch_first=True)
+            self.fc = nn.Linear(H, H)
+
+        def forward(self, x):
+            return self.fc(self.lstm(x)[0][:, -1, :])
+
+    params = init_params(C, H, L, H, None, seed=47)
+    rng = np.random.default_rng(23)
+    views = [rng.standard_normal((B, 40, C)).astype(np.float32) for _ in range(2)] + \
+            [rng.standard_normal((B, 24, C)).astype(np.float32) for _ in range(4)]
+    torch.manual_seed(9)
+    with _default_dtype(torch.float64):
+        head_s = dn["DINOHead"](H, OUT, nlayers=3, hidden_dim=48, bottleneck_dim=16)
+        head_t = dn["DINOHead"](H, OUT, nlayers=3, hidden_dim=48, bottleneck_dim=16)
+        student = ru.MultiCropWrapper(_load_into(Backbone(), params, torch.float64), head_s).double()
+        teacher = ru.MultiCropWrapper(_load_into(Backbone(), params, torch.float64), head_t).double()
+        teacher.load_state_dict(student.state_dict())
+        crit = dn["DINOLoss"](OUT, 6, 0.04, 0.07, 3, 10).double()
+        vt = [torch.from_numpy(v).double() for v in views]
+        with torch.no_grad():
+            teacher_outputs = torch.stack([teacher(v) for v in vt[:2]], dim=0)
+        student_outputs = torch.stack([student(v) for v in vt], dim=0)
+        loss = crit(student_outputs, teacher_outputs, 0)
+        loss.backward()
+    out = dict(dims=np.array([B, C, H, L, OUT]), seed_params=np.array(47), loss=np.array(loss.item()),
+               center=crit.center.numpy().copy(), student_out=student_outputs.detach().numpy())
+    for i, v in enumerate(views):
+        out[f"view{i}"] = v
+    for k, v in student.state_dict().items():
+        if k.startswith("head."):
+            out["sd__" + k] = v.numpy()
+    for k, p in student.named_parameters():
+        if p.grad is not None:
+            out["grad__" + k] = p.grad.numpy()
+    _save("ref_dino_step.npz", out)
+
+
 # ------------------------------------------------------------------------------------------------
 # retrieval acceptance set (north star: bf16 top-1 within +-0.5 % of the CPU reference)
 # ------------------------------------------------------------------------------------------------
 def ref_retrieval(n_gallery=2048, n_query=512):
     """The reference CPU path (scipy sosfilt + z-score -> the reference's LSTMModel, torch f32, eval) embeds a seeded
     clustered set at cfg2; stored: its top-5 neighbour lists / top-1 (exact L2 in f64), labels, a sample of the
-    embeddings.  Inputs are regenerated from the seed at test time (oracle.eeg_filter.clustered_eeg)."""
+    embeddings.  Inputs are regenerated from the seed at test time (cerebralsignalnetworks_amd.dataset.clustered_eeg)."""
     from oracle.lstm import init_params
     from oracle import cpu_path, eeg_filter, retrieval
-    from oracle.eeg_filter import clustered_eeg
+    from cerebralsignalnetworks_amd.dataset import clustered_eeg
     C, T, H, L, D = 128, 500, 768, 2, 384
     ns = lift("LSTMDistillRetreival.py", ["LSTMModel"])
     params = init_params(C, H, L, D, None, seed=43)
@@ -467,6 +524,9 @@ if __name__ == "__main__":
         ref_losses()
         ref_barlow_2rank()
         ref_preproc()
+        ref_dino_step()
+    if what in ("dino",):
+        ref_dino_step()
     if what in ("cfg2", "all"):
         ref_lstm_full("cfg2", 8, 500, 128, 768, 2, 384, seed_x=31)
     if what in ("cfg4", "all"):

@@ -14,7 +14,8 @@ import pytest
 import torch
 
 from cerebralsignalnetworks_amd import cabi, Model, CosineSimilarityLoss, EEGFilters
-from oracle import eeg_filter, lstm
+from cerebralsignalnetworks_amd.dataset import clustered_eeg
+from oracle import lstm
 
 pytestmark = pytest.mark.gpu
 
@@ -128,7 +129,7 @@ def test_bf16_retrieval_top1_within_half_percent_of_cpu_reference(cuda, golden):
     LSTM (bf16 fast path, and the f32 path) -> csn_l2_topk."""
     g = golden("ref_retrieval_cfg2.npz")
     ng, nq = int(g["n_gallery"]), int(g["n_query"])
-    x, labels = eeg_filter.clustered_eeg(ng + nq, seed=int(g["seed"]), snr=float(g["snr"]))
+    x, labels = clustered_eeg(ng + nq, seed=int(g["seed"]), snr=float(g["snr"]))
     np.testing.assert_array_equal(labels, g["labels"])
     C, T, H, L, D = 128, 500, 768, 2, 384
     p = lstm.init_params(C, H, L, D, None, seed=43)
@@ -215,3 +216,42 @@ def test_plans_are_independent_across_streams_and_threads(cuda):
         for feat, grad in outs[i]:
             np.testing.assert_array_equal(feat, alone[i][0])
             np.testing.assert_array_equal(grad, alone[i][1])
+
+
+def test_dino_self_distillation_step_matches_reference_fixture(cuda, golden):
+    """f4 (LstmDistillation.py:518-596): one step of the DINO trainer -- student over 2 global + 4 local temporal
+    views, teacher over the 2 global ones, DINOLoss, backward -- on the HIP LSTM (f32 path), against the fixture made
+    by executing the reference's MultiCropWrapper / DINOHead / DINOLoss (make_ref_goldens.ref_dino_step)."""
+    from cerebralsignalnetworks_amd.dino import DINOHead, DINOLoss, MultiCropWrapper
+    g = golden("ref_dino_step.npz")
+    B, C, H, L, OUT = (int(v) for v in g["dims"])
+    p = lstm.init_params(C, H, L, H, None, seed=int(g["seed_params"]))
+    head_sd = {k[len("sd__head."):]: torch.from_numpy(g[k]).float() for k in g.files if k.startswith("sd__head.")}
+
+    def build():
+        bb = Model(input_size=C, lstm_size=H, lstm_layers=L, output_size=H, include_top=False, compute_dtype=torch.float32)
+        bb.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in p.items()})
+        head = DINOHead(H, OUT, nlayers=3, hidden_dim=48, bottleneck_dim=16)
+        head.load_state_dict(head_sd)
+        return MultiCropWrapper(bb, head).to(cuda)
+
+    student, teacher = build(), build()
+    crit = DINOLoss(OUT, 6, 0.04, 0.07, 3, 10).to(cuda)
+    views = [torch.from_numpy(g[f"view{i}"]).to(cuda) for i in range(6)]
+    with torch.no_grad():
+        teacher_outputs = torch.stack([teacher(v) for v in views[:2]], dim=0)
+    student_outputs = torch.stack([student(v) for v in views], dim=0)
+    loss = crit(student_outputs, teacher_outputs, 0)
+    loss.backward()
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(student_outputs.detach().cpu().numpy(), g["student_out"], atol=2e-5)
+    assert abs(loss.item() - float(g["loss"])) < 1e-5
+    np.testing.assert_allclose(crit.center.cpu().numpy(), g["center"], atol=1e-6)
+    checked = 0
+    for name, par in student.named_parameters():
+        key = "grad__" + name
+        if key in g.files:
+            want = g[key]
+            np.testing.assert_allclose(par.grad.cpu().numpy(), want, atol=1e-4 * max(1e-3, np.abs(want).max()), err_msg=name)
+            checked += 1
+    assert checked >= 14

@@ -205,3 +205,129 @@ def test_distributed_retrieval_eval_two_process_gloo():
         assert out[r][3] == (len(qry), 5)
     assert out[0] == out[1]
 
+
+
+# ---- Barlow-Twins loss over two ranks (net.py:33-42): the product's loss + DDP-mean against the reference's run ----
+def _barlow_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    from cerebralsignalnetworks_amd.losses import BarlowTwinsLoss
+    g = np.load(os.path.join(ROOT, "tests", "golden", "ref_barlow_2rank.npz"))
+    n = g["z1"].shape[0] // world
+    a = torch.from_numpy(g["z1"][rank * n:(rank + 1) * n]).requires_grad_(True)
+    b = torch.from_numpy(g["z2"][rank * n:(rank + 1) * n]).requires_grad_(True)
+    crit = BarlowTwinsLoss(g["z1"].shape[1], g["z1"].shape[0]).double().train()      # batch_size = GLOBAL batch
+    loss = crit(a, b)
+    loss.backward()
+    out[rank] = (loss.item(), a.grad.numpy().copy(), b.grad.numpy().copy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_barlow_loss_two_process_gloo_matches_reference_run():
+    """Fixture = the reference's BarlowTwins.forward executed on two gloo ranks (make_ref_goldens.py): the in-place
+    all_reduce of c is invisible to autograd, so each rank's gradient goes through its own term only (and DDP then
+    averages parameter gradients).  The product's all-reduce must have an identity backward to match."""
+    g = np.load(os.path.join(ROOT, "tests", "golden", "ref_barlow_2rank.npz"))
+    world, port = 2, 29615
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_barlow_worker, args=(world, port, out), nprocs=world, join=True)
+    for r in range(world):
+        loss, g1, g2 = out[r]
+        np.testing.assert_allclose(loss, g[f"loss_r{r}"], rtol=1e-12)
+        np.testing.assert_allclose(g1, g[f"g1_r{r}"], atol=1e-13)
+        np.testing.assert_allclose(g2, g[f"g2_r{r}"], atol=1e-13)
+
+
+# ---- extract_features (PerilsEEGDataset.py:168-226): frozen teacher over all images, gathered on every rank -----------
+class _TeacherStandIn(torch.nn.Module):
+    """A frozen 'teacher' for the plumbing test: a fixed linear map of the image tensor (DINOv2 needs a network)."""
+
+    def __init__(self):
+        super().__init__()
+        g = torch.Generator().manual_seed(5)
+        self.w = torch.nn.Parameter(torch.randn(12, 7, generator=g), requires_grad=False)
+
+    def forward(self, x):
+        return x.reshape(x.shape[0], -1)[:, :12] @ self.w
+
+
+def _make_image_dataset(tmp, n=11):
+    from PIL import Image
+    rng = np.random.default_rng(2)
+    names = []
+    for i in range(n):
+        wnid = f"n0{i % 3}"
+        os.makedirs(os.path.join(tmp, wnid), exist_ok=True)
+        names.append(f"{wnid}_{i}")
+        Image.fromarray(rng.integers(0, 255, (4, 4, 3), dtype=np.uint8)).save(os.path.join(tmp, wnid, f"{wnid}_{i}.JPEG"))
+    items = [{"eeg": torch.randn(4, 30, generator=torch.Generator().manual_seed(i)), "image": i, "label": i % 3, "subject": 1}
+             for i in range(n)]
+    path = os.path.join(tmp, "eeg.pth")
+    torch.save({"dataset": items, "labels": ["n00", "n01", "n02"], "images": names}, path)
+    return path
+
+
+def _to_tensor(img):
+    return torch.from_numpy(np.asarray(img, dtype=np.float32).copy()).permute(2, 0, 1) / 255.0
+
+
+def _extract_worker(rank, world, port, tmp, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    from cerebralsignalnetworks_amd.dataset import EEGDataset
+    ds = EEGDataset(eeg_signals_path=os.path.join(tmp, "eeg.pth"), imagesRoot=tmp, time_low=0, time_high=30,
+                    device=torch.device("cpu"), preprocessin_fn=_to_tensor)
+    ds.extract_features(_TeacherStandIn(), batch_size=4)
+    out[rank] = ds.features_all.numpy().copy()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_extract_features_single_and_two_process_gloo(tmp_path):
+    from cerebralsignalnetworks_amd.dataset import EEGDataset
+    tmp = str(tmp_path)
+    path = _make_image_dataset(tmp)
+    ds = EEGDataset(eeg_signals_path=path, imagesRoot=tmp, time_low=0, time_high=30, device=torch.device("cpu"),
+                    preprocessin_fn=_to_tensor)
+    assert not ds.image_features_extracted and ds[0][4] == []
+    teacher = _TeacherStandIn()
+    ds.extract_features(teacher, batch_size=4)
+    want = torch.stack([teacher(ds._load_image(i)[None])[0] for i in range(len(ds))]).numpy()
+    np.testing.assert_allclose(ds.features_all.numpy(), want, atol=1e-6)
+    assert ds.image_features_extracted and ds[3][4].shape == (7,)
+    world, port = 2, 29617
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_extract_worker, args=(world, port, tmp, out), nprocs=world, join=True)
+    for r in range(world):                        # every rank ends with the whole table, in dataset order
+        np.testing.assert_allclose(out[r], want, atol=1e-6)
+
+
+# ---- the Spampinato flavour (utils/EEGDataset.py:52-53,99-128): split file, subject filter, per-channel normalisation ---
+def test_spampinato_split_subject_filter_and_dataset_level_norm(tmp_path):
+    from utils.EEGDataset import EEGDataset
+    g = torch.Generator().manual_seed(1)
+    items = [{"eeg": torch.randn(5, 40, generator=g) * 3 + 1, "image": k % 4, "label": k % 2, "subject": 1 + k % 3}
+             for k in range(12)]
+    means, stds = torch.randn(5, 1, generator=g), torch.rand(5, 1, generator=g) + 0.5
+    torch.save({"dataset": items, "labels": ["n01", "n02"], "images": ["n01_a", "n02_b", "n01_c", "n02_d"],
+                "means": means, "stddevs": stds}, tmp_path / "eeg.pth")
+    torch.save({"splits": [{"train": [0, 1, 2, 3, 4, 5, 6, 7], "val": [8, 9], "test": [10, 11]}]}, tmp_path / "splits.pth")
+    kw = dict(eeg_signals_path=str(tmp_path / "eeg.pth"), eeg_splits_path=str(tmp_path / "splits.pth"),
+              imagesRoot=str(tmp_path), time_low=5, time_high=35, device=torch.device("cpu"))
+    ds = EEGDataset(subset="train", subject=2, **kw)                       # subject != 0: that subject only
+    keep = [k for k in range(8) if items[k]["subject"] == 2]
+    assert len(ds) == len(keep) and ds.subjects.tolist() == [2] * len(keep)
+    np.testing.assert_array_equal(ds[0][0].numpy(), items[keep[0]]["eeg"].t()[5:35].numpy())
+    ds = EEGDataset(subset="train", subject=0, exclude_subjects=[3], **kw)  # subject == 0: all but the excluded ones
+    keep = [k for k in range(8) if items[k]["subject"] != 3]
+    assert len(ds) == len(keep) and 3 not in ds.subjects.tolist()
+    assert len(EEGDataset(subset="test", subject=0, **kw)) == 2
+    ds = EEGDataset(subset="val", subject=0, apply_norm_with_stds_and_means=True, **kw)
+    want = ((items[8]["eeg"] - means) / stds).t()[5:35]                     # (eeg - means) / stddevs at load, :104-105
+    np.testing.assert_allclose(ds[0][0].numpy(), want.numpy(), atol=1e-6)
+    assert ds[0][1]["ClassId"] == 0 and ds.getLabelbyIndex(1)["ClassId"] == 1
