@@ -29,6 +29,9 @@ __device__ __forceinline__ void beside_glds16(const void* g, void* l) {
 
 // `smem`: the workgroup's dynamic LDS (at LDS offset 0, >= kBesideLdsBytes); worker = this workgroup's index
 // among the nworkers workgroups that share the GEMM (workgroups of one XCD should have consecutive indices).
+// g.counter != null: tiles are handed out by an atomic counter (one word per GEMM, zeroed by the host), so workgroups
+// of different speed -- including recurrence workgroups that have finished their chunk -- share the work evenly; the
+// word at smem + kBesideLdsBytes (the caller allocates kBesideLdsBytes + 64) broadcasts the claimed tile.
 __device__ __forceinline__ void beside_gemm_tiles(const BesideGemm& g, char* smem, unsigned worker, unsigned nworkers) {
   constexpr int NSTAGE = kBesideStages;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -41,9 +44,16 @@ __device__ __forceinline__ void beside_gemm_tiles(const BesideGemm& g, char* sme
   const unsigned a_base = (unsigned)((wm * 128 + (lane & 15)) * 128) + ((((unsigned)lane >> 4) ^ sw) << 4);
   const unsigned b_base = 32768u + (unsigned)((wn * 64 + (lane & 15)) * 128) + ((((unsigned)lane >> 4) ^ sw) << 4);
 
-  for (unsigned lid = worker; lid < ntiles; lid += nworkers) {
+  volatile unsigned* const claim = reinterpret_cast<volatile unsigned*>(smem + kBesideLdsBytes);
+  for (unsigned lid = worker;; lid += nworkers) {
+    __syncthreads();     // every wave has left the previous tile's last stage (and has read the previous claim)
+    if (g.counter != nullptr) {
+      if (tid == 0) *claim = __hip_atomic_fetch_add(g.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __syncthreads();
+      lid = *claim;
+    }
+    if (lid >= ntiles) break;
     const int64_t m0 = (int64_t)(lid / ntn) * 256, n0 = (int64_t)(lid % ntn) * 128;
-    __syncthreads();     // every wave has left the previous tile's last stage
     // staging: a 1 KB instruction fills 8 rows x 8 chunks; A has 32 per stage (8 per wave), B 16 (4 per wave);
     // lane -> row r = lane >> 3, LDS chunk position c = lane & 7 <- global chunk c ^ ((row >> 1) & 7)
     const int srow = lane >> 3;
@@ -121,10 +131,21 @@ __device__ __forceinline__ void beside_gemm_tiles(const BesideGemm& g, char* sme
       for (int j = 0; j < 4; ++j) {
         const int64_t n = n0 + wn * 64 + j * 16 + (lane >> 4) * 4;
         if (n + 3 < N) {
-          *reinterpret_cast<float4*>(g.C + m * N + n) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+          float4 o = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+          if (g.bias != nullptr) {
+            const float4 bz = *reinterpret_cast<const float4*>(g.bias + n);
+            o.x += bz.x; o.y += bz.y; o.z += bz.z; o.w += bz.w;
+          }
+          if (g.c_bf16)
+            *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(g.C) + m * N + n) = (bf16x4){(bf16_t)o.x, (bf16_t)o.y, (bf16_t)o.z, (bf16_t)o.w};
+          else
+            *reinterpret_cast<float4*>(g.C + m * N + n) = o;
+        } else if (g.c_bf16) {
+          for (int r = 0; r < 4; ++r)
+            if (n + r < N) reinterpret_cast<bf16_t*>(g.C)[m * N + n + r] = (bf16_t)(acc[i][j][r] + (g.bias != nullptr ? g.bias[n + r] : 0.0f));
         } else {
           for (int r = 0; r < 4; ++r)
-            if (n + r < N) g.C[m * N + n + r] = acc[i][j][r];
+            if (n + r < N) g.C[m * N + n + r] = acc[i][j][r] + (g.bias != nullptr ? g.bias[n + r] : 0.0f);
         }
       }
     }

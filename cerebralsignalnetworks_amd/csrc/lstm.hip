@@ -42,15 +42,17 @@ struct LayerWs {
 };
 struct WsLayout {
   LayerWs layer[8];
-  size_t x_c, x_blk, wih0_blk, dy_tm, tn_scratch, colsum, status, agree, zeros_bh, total;
+  size_t x_c, x_blk, wih0_blk, dy_tm, tn_scratch, colsum, status, agree, tile_ctr, zeros_bh, total;
   bool fuse_x;
   bool il, persist, persist_bwd;
+  bool fwd_ns;             // forward runs the N-split kernel (lstm_fwd_ns.hip), else the K-split one
 };
 
 static WsLayout make_layout(const csnLstmDesc& d, int training, const Options& opt) {
   WsLayout w{};
   w.il = cell_blk_supported(d.H, d.dtype, opt);
-  w.persist = w.il && fwd_persist_supported(d.B, d.H, d.dtype, opt) && d.L <= 4;
+  w.fwd_ns = w.il && fwd_ns_supported(d.B, d.H, d.dtype, opt) && d.L <= 4;
+  w.persist = w.fwd_ns || (w.il && fwd_persist_supported(d.B, d.H, d.dtype, opt) && d.L <= 4);
   w.persist_bwd = w.persist && training && bwd_persist_supported(d.B, d.H, d.dtype, opt);
   size_t off = 0;
   const size_t es = dtype_size(d.dtype);
@@ -105,13 +107,15 @@ static WsLayout make_layout(const csnLstmDesc& d, int training, const Options& o
   w.x_c = take(TB * d.I * es);
   w.status = take(256);
   // (H = 512 excluded: its 64 x 32-unit tile leaves no registers for the W_ih fragments)
-  w.fuse_x = w.persist && d.I % 32 == 0 && d.I <= 128 && d.H != 512 && !opt.no_fuse_x;
+  w.fuse_x = w.persist && !opt.no_fuse_x &&
+             (w.fwd_ns ? (d.I == 128 && d.H <= 768) : (d.I % 32 == 0 && d.I <= 128 && d.H != 512));
   if (w.fuse_x) {
     w.x_blk = take((size_t)d.T * Bpad * d.I * 2);
     w.wih0_blk = take(G * d.I * 2);
   }
   if (w.persist_bwd) w.zeros_bh = take((size_t)d.B * H * 4);
   if (w.persist) w.agree = take(((size_t)d.T + 8) * 8 * sizeof(unsigned long long));   // 8 words per launch
+  if (w.persist) w.tile_ctr = take(((size_t)d.T + 8) * 4 * sizeof(unsigned));          // GEMM tile counters, 4 per launch
   if (training) {
     w.dy_tm = take(TB * H * 4);
     w.tn_scratch = take(tn_bytes);
@@ -593,6 +597,7 @@ static int forward_persist(Plan& P, char* ws, int training, hipStream_t st, Side
     S.wih_blk = nullptr;
     S.bias = nullptr;
     S.I = 0;
+    S.xproj_bf16 = 0;
     if (l == 0 && w.fuse_x) {
       S.x_blk = (const bf16_t*)(ws + w.x_blk);
       S.wih_blk = (const bf16_t*)(ws + w.wih0_blk);
@@ -617,30 +622,71 @@ static int forward_persist(Plan& P, char* ws, int training, hipStream_t st, Side
   int n_launch = 0;
 
   const int max_slots = NL < nch ? NL : nch;
-  const bool grouped = max_slots <= 4 && max_slots * MT <= 8 && fwd_persist_slices(H) <= 32 &&
+  const int fwd_slices = w.fwd_ns ? fwd_ns_slices(H) : fwd_persist_slices(H);
+  auto launch_fwd = [&](const PersistFwdArgs& args, hipStream_t on) {
+    return w.fwd_ns ? launch_fwd_ns(args, on) : launch_fwd_persist(args, on);
+  };
+  const bool grouped = max_slots <= 4 && max_slots * MT <= 8 && fwd_slices <= 32 &&
                        !P.opt.persist_streams;
   if (grouped) {
-    const int ndiag = nch + NL - 1;
+    // CSN_BESIDE_FWD (N-split kernel, H <= 768): 24 of the 32 CUs of an XCD carry a group, the 8 others (and every CU
+    // of an XCD without a group) walk the input-projection GEMM xproj_{l+1}[chunk] = h_l[chunk] W_ih^T + b of the chunk
+    // layer l finished ONE LAUNCH AGO (gemm_beside.h): both of its dependencies are then kernel boundaries, and the
+    // layer above lags two chunks -- the arrangement of the backward launches.  Measured at cfg2 (profiles/r02_c): the
+    // GEMM needs 17 k CU-us as a kernel of its own (67 us on 256 CUs) but 26 k beside the recurrence (4-wave tiles,
+    // per-CU load bandwidth shared with nothing but itself), and a forward launch leaves only 64 CUs x 215 us = 14 k:
+    // the launches stretch to 263 us and the step ends where it started (10.98 vs 10.96 ms).  Not the default.
+    const bool beside = w.fwd_ns && NL > 1 && fwd_slices <= 28 && H % 64 == 0 && P.opt.beside_fwd;
+    const bool xproj_bf16 = beside && P.opt.xproj_bf16;
+    const int lag = beside ? 2 : 1;
+    const int ndiag = nch + lag * (NL - 1);
     const bool try_local = !P.opt.no_xcd_local;
     if (try_local) CSN_HIP_CHECK(hipMemsetAsync(ws + w.agree, 0, (size_t)ndiag * 8 * sizeof(unsigned long long), st));
+    if (beside) CSN_HIP_CHECK(hipMemsetAsync(ws + w.tile_ctr, 0, (size_t)ndiag * 4 * sizeof(unsigned), st));
+    BesideGemm pending[3];
+    int npending = 0;
+    a.grid_slices = 32;
     if ((rc = prof_mark(g_prof, 0, st))) return rc;
     for (int dg = 0; dg < ndiag; ++dg) {
-      int lay[4], ns = 0;
+      int lay[4], chk[4], ns = 0;
       for (int l = 0; l < NL; ++l) {
-        const int c = dg - l;
+        const int c = dg - lag * l;
         if (c < 0 || c >= nch) continue;
         lay[ns] = l;
-        fill_slot(a.slot[ns++], l, c);
+        chk[ns] = c;
+        fill_slot(a.slot[ns], l, c);
+        a.slot[ns].xproj_bf16 = (l > 0 && xproj_bf16) ? 1 : 0;
+        ++ns;
       }
       a.nslots = ns;
       a.xcd_groups = 1;
+      a.ngemm = npending;
+      for (int i = 0; i < npending; ++i) a.gemm[i] = pending[i];
+      npending = 0;
       a.agree = try_local ? (unsigned long long*)(ws + w.agree) + (size_t)dg * 8 : nullptr;
+      if (ns == 0 && a.ngemm == 0) continue;
       if ((rc = prof_pair(g_prof, 0, false, st))) return rc;
-      if ((rc = launch_fwd_persist(a, st))) return rc;
+      if ((rc = launch_fwd(a, st))) return rc;
       if ((rc = prof_pair(g_prof, 0, true, st))) return rc;
       ++n_launch;
-      for (int i = 0; i < ns; ++i)
-        if (lay[i] + 1 < NL && (rc = xproj_gemm(lay[i], dg - lay[i], st))) return rc;
+      for (int i = 0; i < ns; ++i) {
+        const int l = lay[i];
+        if (l + 1 >= NL) continue;
+        if (!beside) {
+          if ((rc = xproj_gemm(l, chk[i], st))) return rc;
+          continue;
+        }
+        const LayerWs& L = w.layer[l];
+        const LayerWs& Ln = w.layer[l + 1];
+        const int t0 = chk[i] * Cz, nst = (t0 + Cz <= T) ? Cz : T - t0;
+        // (xproj in bf16: half the GEMM's C stream and half of what the recurrence reads back per step; the tile
+        // counter lets the recurrence workgroups take tiles once their chunk is done)
+        float* Cx = xproj_bf16 ? (float*)((bf16_t*)(ws + Ln.xproj) + (size_t)t0 * B * G) : (float*)(ws + Ln.xproj) + (size_t)t0 * B * G;
+        pending[npending] = BesideGemm{(const bf16_t*)(ws + L.h_all) + (size_t)(t0 + 1) * B * H, (const bf16_t*)(ws + Ln.wih),
+                                       Cx, nst * B, (int)G, H, (const float*)(ws + Ln.bias),
+                                       (unsigned*)(ws + w.tile_ctr) + (size_t)dg * 4 + npending, xproj_bf16 ? 1 : 0};
+        ++npending;
+      }
     }
     if ((rc = prof_mark(g_prof, 1, st))) return rc;
     g_prof.launches[0] = n_launch;
@@ -651,7 +697,7 @@ static int forward_persist(Plan& P, char* ws, int training, hipStream_t st, Side
 
   // every launch needs ALL its workgroups resident (one per CU): layers on streams of their own may only run side
   // by side while together they fit the chip; otherwise everything goes down the caller's stream, layer after layer
-  if (NL * fwd_persist_slices(H) * MT > 256) side = st;
+  if (NL * fwd_slices * MT > 256) side = st;
   hipStream_t ls[8];
   ls[0] = st;
   for (int l = 1; l < NL; ++l) {
@@ -667,7 +713,7 @@ static int forward_persist(Plan& P, char* ws, int training, hipStream_t st, Side
   for (int c = 0; c < nch; ++c) {
     for (int l = 0; l < NL; ++l) {
       fill_slot(a.slot[0], l, c);
-      if ((rc = launch_fwd_persist(a, ls[l]))) return rc;
+      if ((rc = launch_fwd(a, ls[l]))) return rc;
       ++n_launch;
       if (l + 1 < NL) {
         // layer l finished chunk c -> GEMM xproj_{l+1}[chunk] on the side stream -> layer l+1 may start it
@@ -918,7 +964,7 @@ static int backward_persist(Plan& P, char* ws, const float* dy_last,
       float* Cg = (float*)(ws + L.dx) + (size_t)t_lo * B * H;
       const int64_t Mg = (int64_t)(t_hi - t_lo + 1) * B;
       if (beside) {
-        pending[npending++] = BesideGemm{Ag, (const bf16_t*)(ws + L.wiht), Cg, (int)Mg, H, (int)G};
+        pending[npending++] = BesideGemm{Ag, (const bf16_t*)(ws + L.wiht), Cg, (int)Mg, H, (int)G, nullptr, nullptr, 0};
       } else {
         if ((rc = gemm_nt(Ag, ws + L.wiht, nullptr, Cg, Mg, H, G, CSN_BF16, CSN_F32, 0, st, P.opt))) return rc;
       }

@@ -61,7 +61,7 @@ __device__ __forceinline__ void bstore_b128(__amdgpu_buffer_rsrc_t rsrc, unsigne
 
 template <int NUT, int KS>
 __global__ void __launch_bounds__(256) lstm_bwd_persist_kernel(PersistBwdArgs a) {
-  constexpr int RING = KS < 5 ? KS : 5;          // k-blocks of dgates in flight per wave
+  constexpr int RING = KS >= 32 ? 3 : (KS < 5 ? KS : 5);   // k-blocks of dgates in flight per wave (3 at H = 1024: register budget)
   constexpr int NT = 4 * NUT;                    // accumulator tiles per wave (4 row groups x NUT unit tiles)
   constexpr int QPR = 4 * NUT;                   // unit quads per row of the tile
   constexpr int NPAIR = 64 * QPR;                // (row, unit-quad) pairs
@@ -348,19 +348,19 @@ __global__ void __launch_bounds__(256) lstm_bwd_persist_kernel(PersistBwdArgs a)
 
 bool bwd_persist_supported(int B, int H, int dtype, const Options& opt) {
   if (dtype != CSN_BF16 || opt.no_persist || opt.no_persist_bwd) return false;
-  return H == 128 || H == 256 || H == 384 || H == 512 || H == 768;
+  return H == 128 || H == 256 || H == 384 || H == 512 || H == 768 || H == 1024;
 }
 int bwd_persist_slices(int H) { return H / 32; }
 
 template <int NUT, int KS>
 static int launch_bwd_persist_t(const PersistBwdArgs& a, hipStream_t st) {
   size_t lds = (size_t)4 * 4 * NUT * 65 * sizeof(float4);
-  if (int rc = ensure_dyn_lds<&lstm_bwd_persist_kernel<NUT, KS>>((int)kBesideLdsBytes)) return rc;
+  if (int rc = ensure_dyn_lds<&lstm_bwd_persist_kernel<NUT, KS>>((int)kBesideLdsBytes + 64)) return rc;
   const unsigned nslices = (unsigned)(a.H / (16 * NUT));
   PersistBwdArgs b = a;
   if (b.xcd_groups) {
     if (b.ngemm > 0) {
-      lds = kBesideLdsBytes;                 // the GEMM workers' staging ring; also keeps every workgroup alone on its CU
+      lds = kBesideLdsBytes + 64;            // the GEMM workers' staging ring (+ the claim word); also keeps every workgroup alone on its CU
       if (b.grid_slices < (int)nslices) b.grid_slices = (int)nslices;
     } else {
       b.grid_slices = (int)nslices;
@@ -381,6 +381,7 @@ int launch_bwd_persist(const PersistBwdArgs& a, hipStream_t st) {
   for (int i = 0; i < a.ngemm; ++i)
     CSN_REQUIRE(a.gemm[i].K % 64 == 0 && a.gemm[i].N % 4 == 0 && a.gemm[i].M > 0, "launch_bwd_persist: GEMM %d shape", i);
   switch (a.H) {
+    case 1024: return launch_bwd_persist_t<2, 32>(a, st);
     case 768: return launch_bwd_persist_t<2, 24>(a, st);
     case 512: return launch_bwd_persist_t<2, 16>(a, st);
     case 384: return launch_bwd_persist_t<2, 12>(a, st);

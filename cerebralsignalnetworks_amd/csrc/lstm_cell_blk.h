@@ -40,7 +40,7 @@ struct CellBwdArgs {
 // own chunk of timesteps (a wavefront diagonal over chunks).
 struct PersistFwdSlot {
   const bf16_t* w_blk;     // fragment-major W_hh, interleaved rows [4H, H]
-  const float* xproj;      // [T, B, 4H] interleaved
+  const float* xproj;      // [T, B, 4H] interleaved (float32; bf16 when xproj_bf16)
   bf16_t* gates;           // [T, B, 4H] interleaved, or null
   float* c_all;            // [T+1, B, H]  (slot t+1 = c_t)
   bf16_t* h_all;           // [T+1, B, H]  row-major
@@ -53,11 +53,28 @@ struct PersistFwdSlot {
   const float* bias;       // [4H] interleaved b_ih + b_hh
   int I;
   int t0, nsteps;
+  int xproj_bf16;          // N-split kernel only: xproj holds bf16 (written by the GEMM the previous launch carried)
+};
+// C[M,N] (f32) = A[M,K] * Bt[N,K]^T (+ bias[N]), bf16 operands: run by the workgroups of a weight-stationary launch
+// that have no recurrence work (gemm_beside.h)
+struct BesideGemm {
+  const bf16_t* A;
+  const bf16_t* Bt;
+  float* C;
+  int M, N, K;
+  const float* bias;       // [N] added to every row, or null
+  unsigned* counter;       // atomic tile counter (zeroed by the host), or null: tiles dealt round-robin to the workers
+  int c_bf16;              // != 0: C is bf16 (the forward's input projection, consumed only by lstm_fwd_ns.hip)
 };
 static constexpr int kPersistFlagLine = 32;    // one 128-byte line per (slot, M-tile): at most 32 slices
 struct PersistFwdArgs {
   PersistFwdSlot slot[4];
   int nslots;
+  // N-split kernel only (lstm_fwd_ns.hip): input-projection GEMMs of the chunks the layers below finished one
+  // launch ago, walked by the workgroups of the launch that have no recurrence work; the grid is 8 * grid_slices
+  BesideGemm gemm[3];
+  int ngemm;
+  int grid_slices;
   // xcd_groups != 0: 1-D grid of 8 * nslices workgroups; the workgroups that share (blockIdx.x % 8) form one
   // hand-off group (a slot's M-tile) -- under the round-robin dispatch they share an XCD, which each group
   // verifies at run time through agree[group] (zeroed, one set of 8 words per launch) before it uses the
@@ -69,6 +86,10 @@ struct PersistFwdArgs {
   int B, H, T, Bpad, MT;
 };
 bool fwd_persist_supported(int B, int H, int dtype, const Options& opt);
+// N-split weight-stationary forward (lstm_fwd_ns.hip): the default where it applies
+bool fwd_ns_supported(int B, int H, int dtype, const Options& opt);
+int fwd_ns_slices(int H);
+int launch_fwd_ns(const PersistFwdArgs& a, hipStream_t st);
 int fwd_persist_slices(int H);   // workgroups per hand-off group
 int launch_fwd_persist(const PersistFwdArgs& a, hipStream_t st);
 
@@ -86,14 +107,6 @@ struct PersistBwdSlot {
   bf16_t* dg_blk_all;      // [T][Bpad * 4H] fragment-major slabs (slot t = dgates_t); never reused in a backward
   unsigned* flags;         // [T][MT][kPersistFlagLine], zeroed per backward
   int t_hi, nsteps;        // steps t_hi, t_hi - 1, ..., t_hi - nsteps + 1
-};
-// C[M,N] (f32) = A[M,K] * Bt[N,K]^T, bf16 operands: run by the workgroups of a backward launch that have no
-// recurrence work (gemm_beside.h)
-struct BesideGemm {
-  const bf16_t* A;
-  const bf16_t* Bt;
-  float* C;
-  int M, N, K;
 };
 struct PersistBwdArgs {
   PersistBwdSlot slot[4];

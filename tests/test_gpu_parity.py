@@ -489,8 +489,22 @@ def test_fast_path_matches_oracle_and_v1(cuda, B, T, C, H, L, chunk):
     # launches, forward and backward
     # (and with layer 0's input projection as a separate GEMM instead of fused into its kernel, which moves the
     # x W_ih^T products into the recurrent sum)
-    exact = dict(CSN_NO_ROTATE="1", CSN_NO_FUSE_X="1")
+    # (the K-split weight-stationary forward: the default N-split kernel keeps each complete K sum in one
+    # accumulator instead of four K-quarter partials reduced through LDS, a different -- equally valid -- order)
+    exact = dict(CSN_NO_ROTATE="1", CSN_NO_FUSE_X="1", CSN_FWD_KSPLIT="1")
     norot = run(**exact)
+    # the N-split forward kernel (lstm_fwd_ns.hip; the default only at H = 1024): its variants agree bit for bit --
+    # one launch per layer on its own stream, the layer-above input-projection GEMM carried inside the launches
+    # (tiles claimed through an atomic counter) -- and it agrees with the K-split kernel to bf16 rounding
+    ns = run(CSN_FWD_NSPLIT="1")
+    _assert_same_bits(ns["y_all"], run(CSN_FWD_NSPLIT="1", CSN_PERSIST_STREAMS="1")["y_all"], "ns streams: y_all")
+    ns_beside = run(CSN_FWD_NSPLIT="1", CSN_BESIDE_FWD="1")
+    for k in ns:
+        _assert_same_bits(ns[k], ns_beside[k], f"ns beside: {k}")
+    ns_bf16x = run(CSN_FWD_NSPLIT="1", CSN_BESIDE_FWD="1", CSN_XPROJ_BF16="1")
+    for k in ns:
+        assert _rel(ns[k], fast[k]) < 1e-2, (k, _rel(ns[k], fast[k]))
+        assert _rel(ns_bf16x[k], fast[k]) < 2e-2, (k, _rel(ns_bf16x[k], fast[k]))
     # (streams: one forward launch per layer on its own stream instead of the grouped launch, per-diagonal backward)
     for name, other in (("diag", run(CSN_NO_PERSIST="1", **exact)),
                         ("diag_bwd", run(CSN_NO_PERSIST_BWD="1", **exact)),

@@ -15,13 +15,20 @@ x = torch.randn(B, C, T, device=dev); tg = torch.randn(B, D, device=dev)
 lib = cabi.load()
 lib.csn_debug_read_pstamps.argtypes = [ctypes.POINTER(ctypes.c_ulonglong)]
 lib.csn_debug_read_bstamps.argtypes = [ctypes.POINTER(ctypes.c_ulonglong)]
-buf = (ctypes.c_ulonglong * 8)()
+lib.csn_debug_read_nstamps.argtypes = [ctypes.POINTER(ctypes.c_ulonglong)]
+buf = (ctypes.c_ulonglong * 16)()
 for it in range(4):
     tr.train_step(x, tg)
     torch.cuda.synchronize()
     # the stamping workgroup (blockIdx.x == 11) belongs to ONE layer's group: sums are over that layer's T steps
-    for name, fn in (("fwd", lib.csn_debug_read_pstamps), ("bwd", lib.csn_debug_read_bstamps)):
+    for name, fn in (("fwd-ksplit", lib.csn_debug_read_pstamps), ("fwd-nsplit", lib.csn_debug_read_nstamps),
+                     ("bwd", lib.csn_debug_read_bstamps)):
         fn(buf)
         per = [buf[i] * 0.01 / T for i in range(6)]
-        print("step %d %s per-step us: wait %.2f | loads+mfma %.2f | lds %.2f | epilogue %.2f | drain %.2f | signal %.2f | sum %.2f | prologue per launch %.1f us"
+        if sum(buf[i] for i in range(7)) == 0:
+            continue
+        if name == "fwd-nsplit":
+            print("   nsplit detail per-step us: dma issue %.2f | x-mfma + input request %.2f | wait g0 %.2f | g0 mfma + wait g1 %.2f | g1,g2 mfma + waits %.2f | (g3 mfma in loads+mfma rest)"
+                  % tuple(buf[i] * 0.01 / T for i in (8, 9, 10, 11, 12)))
+        print("step %d %s per-step us: wait %.2f | loads+mfma %.2f | lds/gate-math %.2f | epilogue %.2f | drain %.2f | signal %.2f | sum %.2f | prologue per launch %.1f us"
               % (it, name, *per, sum(per), buf[6] * 0.01 / 16), flush=True)
