@@ -72,9 +72,28 @@ __device__ __forceinline__ f32x4 ns_bload_nt_f32x4(__amdgpu_buffer_rsrc_t rsrc, 
 }
 __device__ __forceinline__ bf16x8 ns_lds_read_b128(unsigned addr) {
   bf16x8 v;
+#if defined(CSN_NS_ABL) && CSN_NS_ABL >= 2
+  v = __builtin_bit_cast(bf16x8, (nu32x4){addr, addr + 1u, addr + 2u, addr + 3u});   // ablation (timing only): no LDS reads
+#else
   asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+#endif
   return v;
 }
+// The MFMA in inline asm with the stationary operand constrained to the ACCUMULATOR registers.  Left to the compiler,
+// the 8 * H/32 weight registers of a wave overflow the 256 architectural VGPRs, are parked in AGPRs as "spills" and
+// copied back (8 v_accvgpr_read per k-block) in front of the MFMAs that use them: the MFMA phase of a step ran at 40
+// cycles per MFMA instead of 16 (in-kernel stamps with the loads and the LDS reads ablated: unchanged).  CDNA3/4 MFMAs
+// read A/B operands from AGPRs directly, so the weights simply LIVE there.  AIA: the accumulator is in AGPRs too
+// (H <= 768: 8 * 24 + 32 + 32 <= 256); at H = 1024 the weights alone fill the 256 AGPRs and it stays in VGPRs.
+template <bool AIA>
+__device__ __forceinline__ void ns_mfma(f32x4& acc, const bf16x8& w, const bf16x8& h) {
+  if constexpr (AIA) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "a"(w), "v"(h));
+  else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "a"(w), "v"(h));
+}
+// (the hazard recogniser does not see inside inline asm: explicit wait states where a VALU result feeds the first MFMA
+// of a phase, and where the last MFMA's result is read back -- 16-pass MFMA: up to 18 wait states)
+__device__ __forceinline__ void ns_mfma_fence() { asm volatile("s_nop 15\n\ts_nop 7" ::: "memory"); }
+
 template <bool WT>
 __device__ __forceinline__ void ns_store_b128(__amdgpu_buffer_rsrc_t rsrc, unsigned byte_off, const nu32x4& v) {
   __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, (int)byte_off, 0, WT ? 16 : 0);   // sc1 = write-through
@@ -113,6 +132,7 @@ template <int KB, bool FUSED>
 __device__ __forceinline__ void ns_recurrence(const PersistFwdArgs& a, const PersistFwdSlot& S, char* smem, int slice,
                                               int mt, bool local) {
   constexpr int GI = KB / 4;                       // k-blocks per DMA group = DMA instructions per wave and group
+  constexpr bool AIA = KB <= 24;                   // accumulators in AGPRs beside the weights (ns_mfma)
   constexpr int P = FUSED ? 16 : 8;                // 16-byte registers of one input request
   static_assert(KB % 4 == 0, "4 load groups");
   const int B = a.B, H = a.H, MT = a.MT;
@@ -228,6 +248,7 @@ __device__ __forceinline__ void ns_recurrence(const PersistFwdArgs& a, const Per
     for (int rg = 0; rg < 4; ++rg)
 #pragma unroll
       for (int j = 0; j < 2; ++j) acc[rg][j] = FUSED ? biasv[j] : nxt[rg * 2 + j];      // plain: the sum starts from the input projection
+    ns_mfma_fence();
 
     // LDS address of this lane's 16 bytes in block 0; the opaque zero is re-made every step so that the 4 KB fragment
     // addresses derived from it stay one add each instead of being hoisted into 4 KB registers for good
@@ -243,6 +264,9 @@ __device__ __forceinline__ void ns_recurrence(const PersistFwdArgs& a, const Per
     int kb_next = rot;                                       // k-block of walk position p, kept as a running scalar
     const int sbase = __builtin_amdgcn_readfirstlane((int)(((size_t)t * slab + (size_t)((m0 >> 4) + wave) * KB * 512) * 2));
     auto issue_group = [&](int buf) {
+#if defined(CSN_NS_ABL) && CSN_NS_ABL >= 1
+      return;                                               // ablation (timing only): no h loads
+#endif
 #pragma unroll
       for (int i = 0; i < GI; ++i) {
         stg[buf][i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(hdst_rsrc, lane * 16, sbase + kb_next * 1024, 16));
@@ -276,9 +300,7 @@ __device__ __forceinline__ void ns_recurrence(const PersistFwdArgs& a, const Per
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg)
 #pragma unroll
-          for (int j = 0; j < 2; ++j)
-            acc[rg][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wih[kb][j], __builtin_bit_cast(bf16x8, nxt[rg * 4 + kb]),
-                                                                 acc[rg][j], 0, 0, 0);
+          for (int j = 0; j < 2; ++j) ns_mfma<AIA>(acc[rg][j], wih[kb][j], __builtin_bit_cast(bf16x8, nxt[rg * 4 + kb]));
       __builtin_amdgcn_sched_barrier(0);
       CSN_NSTAMP(9);   // x MFMAs
     } else {
@@ -317,8 +339,7 @@ __device__ __forceinline__ void ns_recurrence(const PersistFwdArgs& a, const Per
 #pragma unroll
           for (int rg = 0; rg < 4; ++rg)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
-              acc[rg][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[p][j], hf[i % HD][rg], acc[rg][j], 0, 0, 0);
+            for (int j = 0; j < 2; ++j) ns_mfma<AIA>(acc[rg][j], wreg[p][j], hf[i % HD][rg]);
           __builtin_amdgcn_sched_barrier(0);
         }
       };
@@ -327,9 +348,11 @@ __device__ __forceinline__ void ns_recurrence(const PersistFwdArgs& a, const Per
         // group g has landed in this wave's registers (the compiler counts the vmcnt: only the next group's loads are
         // younger) -> into the tile; its registers take group g + 2; then the MFMAs of group g - 1, published by the
         // barrier of the round before; then this round's barrier publishes group g
+#if !defined(CSN_NS_ABL) || CSN_NS_ABL < 1
 #pragma unroll
         for (int i = 0; i < GI; ++i)
           *reinterpret_cast<bf16x8*>(smem + ((size_t)wave * KB + g * GI + i) * 1024 + lane * 16) = stg[g % SB][i];
+#endif
         __builtin_amdgcn_sched_barrier(0);
         if (g + SB < 4) issue_group(g % SB);
         __builtin_amdgcn_sched_barrier(0);
@@ -341,6 +364,7 @@ __device__ __forceinline__ void ns_recurrence(const PersistFwdArgs& a, const Per
       }
       mfma_group(3);
     }
+    ns_mfma_fence();
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (FUSED) {
       // (fused layer 0: the 64 registers of x are free only now; requested later than this -- after the gate math --
@@ -420,9 +444,306 @@ __device__ __forceinline__ void ns_recurrence(const PersistFwdArgs& a, const Per
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// K2 x N2 form (H % 24 == 0: 384, 768): the MFMA phase of a step runs at the MFMA rate -- 14 ns per
+// v_mfma_f32_16x16x32_bf16 at the clock the chip holds under MFMA load (tools/mfma_rate.hip: 16.3 shader cycles =
+// 12 - 14 ns, i.e. about 1.2 GHz) -- so the step time is (MFMAs per wave) x 14 ns + everything that is not MFMA.  The
+// N-split body above has the cheap "everything else" (2.7 us against 4.4 us of the K-split kernel) but, with 32
+// units per workgroup, only 24 workgroups per group: 192 MFMAs per wave = 2.7 us where the K-split kernel's 32
+// workgroups need 144 = 2.0 us.  This body keeps 32 workgroups per group (64 rows x 24 units = 6 gate-row tiles):
+// wave (kh, th) multiplies K-half kh of tiles 3 th .. 3 th + 2 (144 MFMAs, 36 weight fragments = 144 AGPRs), the two
+// K-halves swap the half of their partial tiles the other one finishes (24 KB through LDS instead of the 100 KB
+// 4-way reduction), and each wave runs the gate math in place on 2 row groups x 3 tiles = 6 cells per lane.
+template <int KB, bool FUSED>
+__device__ __forceinline__ void kn_recurrence(const PersistFwdArgs& a, const PersistFwdSlot& S, char* smem, int slice,
+                                              int mt, bool local) {
+  constexpr int KH = KB / 2;                       // k-blocks of one K-half
+  constexpr int GQ = KH / 4;                       // k-blocks per load group (4 groups); a wave loads 2 row groups of them
+  constexpr int GI = 2 * GQ;                       // loads per wave and group
+  static_assert(KH % 4 == 0, "4 load groups per K-half");
+  constexpr int P = FUSED ? 8 : 6;                 // 16-byte registers of one input request
+  const int B = a.B, H = a.H, MT = a.MT;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kh = wave >> 1, th = wave & 1;
+#ifdef CSN_PSTAMPS
+  unsigned long long last_ = wall_clock64();
+#endif
+  const int nslices = H / 24;
+  const int u0 = slice * 24, m0 = mt * 64;
+  const size_t slab = (size_t)a.Bpad * H;
+  bf16_t* const gates = S.gates;
+  float* const c_all = S.c_all;
+  bf16_t* const h_all = S.h_all;
+  unsigned* const flags = S.flags + (size_t)mt * kPersistFlagLine;
+  const size_t flag_step = (size_t)MT * kPersistFlagLine;
+  const int t_first = S.t0, nsteps = S.nsteps;
+  constexpr int xkb = 4;                               // fused form: I = 128 (checked by the launcher)
+  // LDS: h tile [2 kh][4 rg][KH] 1 KB blocks | partial-sum exchange 4 x 6 KB | transpose area
+  char* const exch = smem + (size_t)KB * 4096;
+  char* const stage = exch + 4 * 6144;
+  const unsigned lds_base = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)smem;
+
+  // ---- stationary operands: K-half kh of this wave's 3 gate-row tiles; register p holds k-block kh KH + (p + rot) % KH
+  const int rot = a.rotate ? __builtin_amdgcn_readfirstlane((slice * KH) / nslices) : 0;
+  const int tile0 = 6 * slice + 3 * th;                // first of this wave's three 16-row tiles of the interleaved 4H axis
+  bf16x8 wreg[KH][3];
+#pragma unroll
+  for (int p = 0; p < KH; ++p) {
+    int kb = p + rot;
+    kb = (kb >= KH ? kb - KH : kb) + kh * KH;
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+      wreg[p][j] = *reinterpret_cast<const bf16x8*>(S.w_blk + ((int64_t)(tile0 + j) * KB + kb) * 512 + lane * 8);
+  }
+  bf16x8 wih[FUSED ? 2 : 1][3];                        // fused: x k-blocks 2 kh, 2 kh + 1
+  f32x4 biasv[3];
+  if constexpr (FUSED) {
+#pragma unroll
+    for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+        wih[k2][j] = *reinterpret_cast<const bf16x8*>(S.wih_blk + ((int64_t)(tile0 + j) * xkb + 2 * kh + k2) * 512 + lane * 8);
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+      biasv[j] = *reinterpret_cast<const f32x4*>(S.bias + 16 * (size_t)(tile0 + j) + 4 * (lane >> 4));
+  }
+
+  // ---- the 6 cells this lane FINISHES: row groups 2 kh, 2 kh + 1; units u0 + 12 th + 4 j + (lane >> 4)
+  const int unit_q = u0 + 12 * th + (lane >> 4);           // + 4 j
+  int rowc[2];
+#pragma unroll
+  for (int r2 = 0; r2 < 2; ++r2) {
+    const int r = m0 + 16 * (2 * kh + r2) + (lane & 15);
+    rowc[r2] = r < B ? r : B - 1;
+  }
+  float cst[2][3];
+#pragma unroll
+  for (int r2 = 0; r2 < 2; ++r2)
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+      cst[r2][j] = t_first > 0 ? c_all[((size_t)t_first * B + rowc[r2]) * H + unit_q + 4 * j] : 0.0f;
+
+  // next step's input: plain layers the projection of the 6 cells (6 x 16 B); the fused layer 0 the x fragments of
+  // all 4 row groups for this wave's 2 input k-blocks (8 x 16 B)
+  f32x4 nxt[P];
+  const unsigned xslab = FUSED ? (unsigned)a.Bpad * (unsigned)S.I : 0u;
+  const __amdgpu_buffer_rsrc_t in_rsrc = FUSED
+      ? __builtin_amdgcn_make_buffer_rsrc((void*)ns_uniform(S.x_blk), 0, __builtin_amdgcn_readfirstlane((int)((size_t)a.T * xslab * 2)), 0x00020000)
+      : __builtin_amdgcn_make_buffer_rsrc((void*)ns_uniform(S.xproj), 0, __builtin_amdgcn_readfirstlane((int)((size_t)a.T * B * 16 * H)), 0x00020000);
+  int xvoff[2];
+#pragma unroll
+  for (int r2 = 0; r2 < 2; ++r2) xvoff[r2] = (int)(((size_t)rowc[r2] * 4 * H + 4 * (size_t)unit_q) * 4);
+  auto request_input = [&](int t) {
+    if constexpr (FUSED) {
+      const int sbase = __builtin_amdgcn_readfirstlane((int)(((size_t)t * xslab + (size_t)(m0 >> 4) * xkb * 512) * 2) + 2 * kh * 1024);
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg)
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) nxt[rg * 2 + k2] = ns_bload_nt_f32x4(in_rsrc, lane * 16 + (rg * 4 + k2) * 1024, sbase);
+    } else {
+      const int sbase = __builtin_amdgcn_readfirstlane((int)((size_t)t * B * 16 * H));
+#pragma unroll
+      for (int r2 = 0; r2 < 2; ++r2)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) nxt[r2 * 3 + j] = ns_bload_nt_f32x4(in_rsrc, xvoff[r2] + j * 64, sbase);
+    }
+  };
+  request_input(t_first);
+
+  const __amdgpu_buffer_rsrc_t hdst_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc((void*)ns_uniform(S.h_blk_all), 0, __builtin_amdgcn_readfirstlane((int)((size_t)(a.T + 1) * slab * 2)), 0x00020000);
+
+  for (int s = 0; s < nsteps; ++s) {
+    const int t = t_first + s;
+    f32x4 acc[4][3];
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) acc[rg][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    ns_mfma_fence();
+
+    unsigned zero_;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(zero_));
+    const unsigned hbase = lds_base + (unsigned)(kh * 4 * KH * 1024) + (unsigned)lane * 16u + zero_;   // this wave's K-half of the tile
+    // this wave brings in row groups 2 th, 2 th + 1 of K-half kh: registers (sc1 buffer loads) -> ds_write, 4 groups
+    bf16x8 stg[2][GI];
+    int kb_next = rot;
+    const int sbase = __builtin_amdgcn_readfirstlane((int)(((size_t)t * slab + ((size_t)((m0 >> 4) + 2 * th) * KB + kh * KH) * 512) * 2));
+    auto issue_group = [&](int buf) {
+#pragma unroll
+      for (int i = 0; i < GQ; ++i) {
+#pragma unroll
+        for (int r2 = 0; r2 < 2; ++r2)
+          stg[buf][i * 2 + r2] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(hdst_rsrc, lane * 16 + r2 * KB * 1024, sbase + kb_next * 1024, 16));
+        kb_next = kb_next + 1 == KH ? 0 : kb_next + 1;
+      }
+    };
+    if (t > 0) {
+      {
+        const unsigned* fl = flags + (size_t)t * flag_step + (lane < nslices ? lane : 0);
+        const unsigned long long t_begin = wall_clock64();
+        while (!__all(__hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+          __builtin_amdgcn_s_sleep(1);
+          if (__hip_atomic_load(a.error_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+          if (wall_clock64() - t_begin > kNsSpinTimeoutTicks) {
+            __hip_atomic_store(a.error_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+          }
+        }
+      }
+      CSN_NSTAMP(0);   // wait for h_{t-1}
+      issue_group(0);
+      issue_group(1);
+      __builtin_amdgcn_sched_barrier(0);
+      CSN_NSTAMP(8);
+    }
+    if constexpr (FUSED) {
+#pragma unroll
+      for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg)
+#pragma unroll
+          for (int j = 0; j < 3; ++j) ns_mfma<true>(acc[rg][j], wih[k2][j], __builtin_bit_cast(bf16x8, nxt[rg * 2 + k2]));
+      __builtin_amdgcn_sched_barrier(0);
+      CSN_NSTAMP(9);
+      request_input(s + 1 < nsteps ? t + 1 : t);            // (its 8 registers were just consumed)
+      __builtin_amdgcn_sched_barrier(0);
+    }
+
+    if (t > 0) {
+      auto mfma_group = [&](int g) {
+        bf16x8 hf[3][4];
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+          if (d < GQ) {
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) hf[d][rg] = ns_lds_read_b128(hbase + (unsigned)((rg * KH + g * GQ + d) * 1024));
+          }
+#pragma unroll
+        for (int i = 0; i < GQ; ++i) {
+          const int p = g * GQ + i;
+          if (i + 2 < GQ) {
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) hf[(i + 2) % 3][rg] = ns_lds_read_b128(hbase + (unsigned)((rg * KH + p + 2) * 1024));
+          }
+          const int ahead = (GQ - 1 - i) < 2 ? (GQ - 1 - i) : 2;
+          if (ahead == 2) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+          else if (ahead == 1) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+          else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int rg = 0; rg < 4; ++rg)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) ns_mfma<true>(acc[rg][j], wreg[p][j], hf[i % 3][rg]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      };
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+#pragma unroll
+        for (int i = 0; i < GQ; ++i)
+#pragma unroll
+          for (int r2 = 0; r2 < 2; ++r2)
+            *reinterpret_cast<bf16x8*>(smem + ((size_t)(kh * 4 + 2 * th + r2) * KH + g * GQ + i) * 1024 + lane * 16) = stg[g & 1][i * 2 + r2];
+        __builtin_amdgcn_sched_barrier(0);
+        if (g + 2 < 4) issue_group(g & 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (g > 0) mfma_group(g - 1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        CSN_NSTAMP(10 + g > 12 ? 12 : 10 + g);
+      }
+      mfma_group(3);
+    }
+    ns_mfma_fence();
+    __builtin_amdgcn_sched_barrier(0);
+    CSN_NSTAMP(1);     // loads + MFMA
+
+    // ---- the two K-halves swap what the other one finishes: wave (kh, th) gives away row groups 2 (1 - kh) + {0, 1}
+    {
+      f32x4* const mine = reinterpret_cast<f32x4*>(exch + (size_t)wave * 6144);
+      const f32x4* const theirs = reinterpret_cast<const f32x4*>(exch + (size_t)(wave ^ 2) * 6144);
+#pragma unroll
+      for (int r2 = 0; r2 < 2; ++r2)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) mine[(r2 * 3 + j) * 64 + lane] = kh == 0 ? acc[2 + r2][j] : acc[r2][j];   // (static indices: kh is a scalar)
+      __syncthreads();
+      // gate math in place on the 6 finished cells; results into the workgroup's transpose area
+      char* const sg = stage;                                  // gates [64 rows][208 B]: 24 units x (i, f, g, o) bf16
+      char* const sc = stage + 64 * 208;                       // c     [64 rows][112 B]: 24 units f32
+      char* const sh = stage + 64 * 208 + 64 * 112;            // h     [64 rows][ 80 B]: 24 units bf16
+#pragma unroll
+      for (int r2 = 0; r2 < 2; ++r2)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          const f32x4 o = theirs[(r2 * 3 + j) * 64 + lane];
+          const f32x4 own = kh == 0 ? acc[r2][j] : acc[2 + r2][j];
+          const f32x4 in = FUSED ? biasv[j] : nxt[r2 * 3 + j];
+          const f32x4 v = own + o + in;
+          const float gi = fast_sigmoid(v[0]), gf = fast_sigmoid(v[1]), gg = fast_tanh(v[2]), go = fast_sigmoid(v[3]);
+          const float cn = gf * cst[r2][j] + gi * gg;
+          const float hn = go * fast_tanh(cn);
+          cst[r2][j] = cn;
+          const int row = (2 * kh + r2) * 16 + (lane & 15), unit = 12 * th + 4 * j + (lane >> 4);
+          *reinterpret_cast<bf16x4*>(sg + row * 208 + unit * 8) = (bf16x4){(bf16_t)gi, (bf16_t)gf, (bf16_t)gg, (bf16_t)go};
+          *reinterpret_cast<float*>(sc + row * 112 + unit * 4) = cn;
+          *reinterpret_cast<bf16_t*>(sh + row * 80 + unit * 2) = (bf16_t)hn;
+        }
+      if constexpr (!FUSED) {
+        __builtin_amdgcn_sched_barrier(0);
+        request_input(s + 1 < nsteps ? t + 1 : t);          // (its 6 registers were just consumed)
+      }
+      CSN_NSTAMP(2);   // exchange + gate math + transpose writes
+      __syncthreads();
+      // out again with consecutive lanes on consecutive bytes; the hand-off payload first
+      if (tid < 192) {
+        const int row = tid & 63, c8 = tid >> 6;              // 16 consecutive rows of a block are 256 contiguous bytes
+        const nu32x4 v = *reinterpret_cast<const nu32x4*>(sh + row * 80 + c8 * 16);
+        const unsigned hoff = (unsigned)(((size_t)(t + 1) * slab + blk_offset(m0 + row, u0 + 8 * c8, H)) * 2);
+        if (local) ns_store_b128<false>(hdst_rsrc, hoff, v);
+        else ns_store_b128<true>(hdst_rsrc, hoff, v);
+        const int row2 = tid / 3, c2 = tid % 3;
+        if (m0 + row2 < B)
+          nt_store(reinterpret_cast<nu32x4*>(h_all + ((size_t)(t + 1) * B + m0 + row2) * H + u0 + 8 * c2),
+                   *reinterpret_cast<const nu32x4*>(sh + row2 * 80 + c2 * 16));
+      }
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int idx = tid + 256 * k, row = idx / 6, ch = idx % 6;
+        if (idx < 384 && m0 + row < B)
+          nt_store(reinterpret_cast<nu32x4*>(c_all + ((size_t)(t + 1) * B + m0 + row) * H + u0 + 4 * ch),
+                   *reinterpret_cast<const nu32x4*>(sc + row * 112 + ch * 16));
+      }
+      if (gates != nullptr) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const int idx = tid + 256 * k, row = idx / 12, ch = idx % 12;
+          if (m0 + row < B)
+            nt_store(reinterpret_cast<nu32x4*>(gates + ((size_t)t * B + m0 + row) * 4 * H + 4 * (size_t)u0 + 8 * ch),
+                     *reinterpret_cast<const nu32x4*>(sg + row * 208 + ch * 16));
+        }
+      }
+    }
+    CSN_NSTAMP(3);     // transpose reads + store issue
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    CSN_NSTAMP(4);     // drain + barrier
+    if (tid == 0) {
+      unsigned* fl = flags + (size_t)(t + 1) * flag_step + slice;
+      if (local) *fl = 1u;
+      else __hip_atomic_store(fl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    CSN_NSTAMP(5);     // signal
+  }
+}
+static constexpr int kKnLdsExtra = 4 * 6144 + 64 * (208 + 112 + 80);      // exchange + transpose area behind the h tile
+
 // FUSE: may a slot of this launch be the fused layer 0?  Whether a workgroup's slot IS fused is a run-time,
 // workgroup-uniform fact (one launch advances layer 0 and the layers above it).
-template <int KB, bool FUSE>
+// KN: the K2 x N2 body (24 units per workgroup) instead of the N-split one (32 units)
+template <int KB, bool FUSE, bool KN>
 __global__ void __launch_bounds__(256) lstm_fwd_ns_kernel(PersistFwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [4 rg][KB] 1 KB blocks of h, then the 28 KB transpose
   const int H = a.H, MT = a.MT;
@@ -430,7 +751,7 @@ __global__ void __launch_bounds__(256) lstm_fwd_ns_kernel(PersistFwdArgs a) {
 #ifdef CSN_PSTAMPS
   const unsigned long long t_entry_ = wall_clock64();
 #endif
-  const int nslices = H >> 5;
+  const int nslices = KN ? H / 24 : H >> 5;
   int grp, slice;
   if (a.xcd_groups) {
     grp = blockIdx.x & 7;
@@ -486,11 +807,15 @@ __global__ void __launch_bounds__(256) lstm_fwd_ns_kernel(PersistFwdArgs a) {
   bool done = false;
   if constexpr (FUSE) {
     if (__builtin_amdgcn_readfirstlane((int)(S.x_blk != nullptr)) != 0) {
-      ns_recurrence<KB, true>(a, S, smem, slice, mt, local);
+      if constexpr (KN) kn_recurrence<KB, true>(a, S, smem, slice, mt, local);
+      else ns_recurrence<KB, true>(a, S, smem, slice, mt, local);
       done = true;
     }
   }
-  if (!done) ns_recurrence<KB, false>(a, S, smem, slice, mt, local);
+  if (!done) {
+    if constexpr (KN) kn_recurrence<KB, false>(a, S, smem, slice, mt, local);
+    else ns_recurrence<KB, false>(a, S, smem, slice, mt, local);
+  }
   // chunk finished: take tiles of the launch's GEMMs that are still unclaimed (counter mode only)
   for (int i = 0; i < a.ngemm; ++i)
     if (a.gemm[i].counter != nullptr) beside_gemm_tiles(a.gemm[i], smem, 0u, 1u);
@@ -502,7 +827,8 @@ static bool ns_device_has_256_cus() {
   return hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus >= 256;
 }
 
-// H / 32 workgroups per hand-off group, each alone on its CU, all of a launch co-resident
+int fwd_ns_slices(int H);
+// all workgroups of a launch co-resident, each alone on its CU
 bool fwd_ns_supported(int B, int H, int dtype, const Options& opt) {
   if (dtype != CSN_BF16 || opt.no_persist || opt.fwd_ksplit) return false;
   if (!(H == 128 || H == 256 || H == 384 || H == 512 || H == 768 || H == 1024)) return false;
@@ -510,15 +836,14 @@ bool fwd_ns_supported(int B, int H, int dtype, const Options& opt) {
   // K-split one stays the default there; the N-split one is the only weight-stationary forward at H = 1024
   if (H != 1024 && !opt.fwd_nsplit) return false;
   if (!ns_device_has_256_cus()) return false;
-  return (H / 32) * ((B + 63) / 64) <= 128;
+  return fwd_ns_slices(H) * ((B + 63) / 64) <= 128;
 }
-int fwd_ns_slices(int H) { return H / 32; }
 
-template <int KB, bool FUSE>
+template <int KB, bool FUSE, bool KN>
 static int launch_ns_t(const PersistFwdArgs& a, hipStream_t st) {
-  size_t lds = (size_t)KB * 4096 + kNsStageBytes;
-  if (int rc = ensure_dyn_lds<&lstm_fwd_ns_kernel<KB, FUSE>>((int)(lds > kBesideLdsBytes + 64 ? lds : kBesideLdsBytes + 64))) return rc;
-  const unsigned nslices = (unsigned)(a.H / 32);
+  size_t lds = (size_t)KB * 4096 + (KN ? kKnLdsExtra : kNsStageBytes);
+  if (int rc = ensure_dyn_lds<&lstm_fwd_ns_kernel<KB, FUSE, KN>>((int)(lds > kBesideLdsBytes + 64 ? lds : kBesideLdsBytes + 64))) return rc;
+  const unsigned nslices = (unsigned)(KN ? a.H / 24 : a.H / 32);
   PersistFwdArgs b = a;
   if (b.xcd_groups) {
     if (b.ngemm > 0) {
@@ -529,14 +854,18 @@ static int launch_ns_t(const PersistFwdArgs& a, hipStream_t st) {
     }
   }
   const unsigned grid = b.xcd_groups ? 8u * (unsigned)b.grid_slices : nslices * (unsigned)(b.MT * b.nslots);
-  lstm_fwd_ns_kernel<KB, FUSE><<<dim3(grid), 256, lds, st>>>(b);
+  lstm_fwd_ns_kernel<KB, FUSE, KN><<<dim3(grid), 256, lds, st>>>(b);
   CSN_LAUNCH_CHECK();
   return CSN_OK;
 }
 
+// which body runs: the K2 x N2 one at H = 768 (32 workgroups per group), else the N-split one
+static bool ns_use_kn(int H) { return H == 768; }
+int fwd_ns_slices(int H) { return ns_use_kn(H) ? H / 24 : H / 32; }
+
 int launch_fwd_ns(const PersistFwdArgs& a, hipStream_t st) {
   CSN_REQUIRE(a.nslots >= (a.ngemm > 0 ? 0 : 1) && a.nslots <= 4 && a.MT >= 1, "launch_fwd_ns: bad slot count");
-  const int ns = a.H / 32;
+  const int ns = fwd_ns_slices(a.H);
   CSN_REQUIRE(ns <= kPersistFlagLine, "launch_fwd_ns: H=%d gives %d slices", a.H, ns);
   if (a.xcd_groups) CSN_REQUIRE(a.nslots * a.MT <= 8, "launch_fwd_ns: groups do not fit 8 XCDs");
   CSN_REQUIRE(a.ngemm >= 0 && a.ngemm <= 3 && (a.ngemm == 0 || a.xcd_groups), "launch_fwd_ns: bad GEMM list");
@@ -545,15 +874,15 @@ int launch_fwd_ns(const PersistFwdArgs& a, hipStream_t st) {
     fused = fused || a.slot[i].x_blk != nullptr;
     CSN_REQUIRE(a.slot[i].x_blk == nullptr || a.slot[i].I == 128, "launch_fwd_ns: the fused input projection takes I = 128");
   }
+  if (a.H == 768) return fused ? launch_ns_t<24, true, true>(a, st) : launch_ns_t<24, false, true>(a, st);
 #define CSN_NS_CASE(KBV)                                                   \
   case KBV * 32:                                                           \
-    return fused ? launch_ns_t<KBV, true>(a, st) : launch_ns_t<KBV, false>(a, st)
+    return fused ? launch_ns_t<KBV, true, false>(a, st) : launch_ns_t<KBV, false, false>(a, st)
   switch (a.H) {
     CSN_NS_CASE(4);
     CSN_NS_CASE(8);
     CSN_NS_CASE(12);
     CSN_NS_CASE(16);
-    CSN_NS_CASE(24);
     CSN_NS_CASE(32);
   }
 #undef CSN_NS_CASE

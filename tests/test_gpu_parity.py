@@ -458,6 +458,9 @@ def _rel(a, b):
                                              (6, 44, 128, 1024, 2, "16"),      # cfg4 width (Spampinato split: H=1024)
                                              (40, 24, 128, 128, 4, "8"),       # 4 layers (TrainSpampinato.py:368)
                                              (130, 33, 16, 512, 2, "32"),
+                                             # the benchmark width: kernels <6,6> forward / <2,24> backward / K2xN2 body of
+                                             # lstm_fwd_ns.hip, one M-tile and all four (8 hand-off groups = 8 XCDs)
+                                             (64, 40, 128, 768, 2, "8"), (256, 24, 128, 768, 2, "8"),
                                              # T*B >= 8192 rows: 256 x 256 weight-gradient kernel + fused bias sums
                                              (64, 130, 32, 256, 2, "32")])
 def test_fast_path_matches_oracle_and_v1(cuda, B, T, C, H, L, chunk):
