@@ -7,14 +7,15 @@ BASELINE.json:north_star.  Only ``tests/``, ``__graft_entry__.smoke()`` and the
 (``cerebralsignalnetworks_amd``) never does and fails loudly when its HIP
 library is missing.
 
-Pinning: the reference has no tests, golden vectors or fixtures of its own
-(SURVEY.md section 4), and most of its modules cannot be imported here
-(faiss / torchvision / models.lstm are absent).  The oracle is therefore pinned
-against outputs of the third-party calls the reference itself makes
-(``scipy.signal.butter/sosfilt/filtfilt``, ``torch.nn.LSTM`` on CPU,
-``torch.nn.CosineSimilarity``, ``F.cross_entropy``, ``nn.KLDivLoss``) and of
-the reference pieces that do import (``utils/EEGFilters.py`` band edges,
-``EEG-BarlowNetworks/optim.py`` LARS, ``utils/utils.py`` cosine_scheduler).
-Those outputs are committed under ``tests/golden/`` with the script that made
-them (``tests/golden/make_goldens.py``).
+Pinning: the oracle is pinned to the reference ITSELF.  The reference has no tests or fixtures of its own
+ and most of its modules cannot be imported here (faiss / torchvision / cv2 / librosa /
+models.lstm at module level), but the class and function bodies on the hot path need only torch / numpy /
+scipy: ``tests/golden/ref_lift.py`` compiles exactly those definitions out of the files where they lie under
+/root/reference (nothing copied, nothing stubbed) and ``tests/golden/make_ref_goldens.py`` executes them on
+seeded inputs in the build container; the outputs are committed as ``tests/golden/ref_*.npz`` and every
+oracle function is checked against them in ``tests/test_ref_pinned.py`` (DESIGN.md section 5 lists fixture ->
+executed definitions).  A second, older set of goldens (``make_goldens.py``) comes from the third-party calls
+the reference makes (scipy.signal, torch.nn.LSTM, ...) and from the reference modules that do import.
+Not executable here and therefore restated only -- "parity unpinned": the faiss search inside ``evaluate``
+(its bookkeeping follows the reference text line by line).
 """

@@ -6,11 +6,11 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 out=${1:-gpurun_out/pmc_traffic.json}
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf gpurun_out/pmcb_$c
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmcb_$c -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing > gpurun_out/pmcb_$c.log 2>&1 || { echo "pass $c failed"; tail -5 gpurun_out/pmcb_$c.log; exit 1; }
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmcb_$c -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-retrieval --no-f32-line > gpurun_out/pmcb_$c.log 2>&1 || { echo "pass $c failed"; tail -5 gpurun_out/pmcb_$c.log; exit 1; }
 done
 python3 - "$out" <<'PY'
 import csv, glob, json, sys, collections
-res = {"command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE (separate passes) --kernel-trace -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing",
+res = {"command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE (separate passes) --kernel-trace -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-retrieval --no-f32-line",
        "units": "counter values are KiB per dispatch; corrected = (2*FETCH_SIZE + WRITE_SIZE)*1024 bytes (gfx950: FETCH_SIZE counts 128-B requests as 64 B)",
        "kernels": {}}
 names = ["lstm_bwd_persist_kernel", "lstm_fwd_persist_kernel", "gemm_nt_256_kernel", "gemm_nt_dma_kernel", "gemm_nt_bf16_kernel",
