@@ -48,6 +48,7 @@ SIGNATURES = {
                                    ctypes.POINTER(_c_void_p), ctypes.POINTER(_c_void_p),
                                    ctypes.POINTER(_c_void_p), ctypes.POINTER(_c_void_p),
                                    _c_void_p, _c_void_p]),
+    "csn_lstm_workspace_init": (_c_int, [_c_void_p, _c_void_p, _c_void_p]),
     "csn_lstm_status_clear": (_c_int, [_c_void_p, _c_void_p, _c_void_p]),
     "csn_lstm_status_read": (_c_int, [_c_void_p, _c_void_p, ctypes.POINTER(_c_int)]),
     "csn_lstm_status_raise": (_c_int, [_c_void_p, _c_void_p, _c_void_p]),
@@ -64,6 +65,7 @@ SIGNATURES = {
     "csn_lstm_cell_backward": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_i64, _c_void_p, _c_void_p, _c_void_p,
                                         _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p]),
     "csn_cosine_loss": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_void_p, _c_void_p, _c_float, _c_void_p]),
+    "csn_rmsprop_step": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_i64, _c_float, _c_float, _c_float, _c_void_p]),
     "csn_barlow_offdiag_sqsum": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_void_p]),
     "csn_l2_topk_scratch_bytes": (_c_size_t, [_c_i64, _c_i64]),
     "csn_l2_topk": (_c_int, [_c_void_p, _c_void_p, _c_i64, _c_i64, _c_int, _c_int, _c_void_p, _c_void_p,
@@ -233,7 +235,8 @@ class LstmPlan:
         off = (-self.workspace.data_ptr()) % 256
         self._ws_ptr = ctypes.c_void_p(self.workspace.data_ptr() + off)
         self.busy = False
-        self.clear_status()          # torch.empty memory: the sticky status word starts at 0
+        with torch.cuda.device(self.device):      # torch.empty memory: status word, zero initial state, ...
+            _check(lib.csn_lstm_workspace_init(self._plan, self._ws_ptr, _stream()))
 
     def __del__(self):
         plan, self._plan = getattr(self, "_plan", None), None
@@ -318,6 +321,16 @@ def cosine_loss(student, teacher, want_grad=True, grad_scale=1.0):
     ds = torch.empty_like(s) if want_grad else None
     _check(load().csn_cosine_loss(_ptr(s), _ptr(t), B, D, _ptr(loss), _ptr(ds), float(grad_scale), _stream()))
     return loss, ds
+
+
+def rmsprop_step(params_flat, grads_flat, square_avg_flat, lr, alpha=0.99, eps=1e-8):
+    """In place, on the current stream: one fused pass over the flat float32 buffers."""
+    _need_cuda(params_flat, grads_flat, square_avg_flat)
+    n = params_flat.numel()
+    assert grads_flat.numel() == n and square_avg_flat.numel() == n
+    assert params_flat.dtype == grads_flat.dtype == square_avg_flat.dtype == torch.float32
+    _check(load().csn_rmsprop_step(_ptr(params_flat), _ptr(grads_flat), _ptr(square_avg_flat), n, float(lr), float(alpha),
+                                   float(eps), _stream()))
 
 
 def barlow_offdiag_sqsum(c):

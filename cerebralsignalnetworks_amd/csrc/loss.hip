@@ -113,3 +113,51 @@ extern "C" int csn_barlow_offdiag_sqsum(const float* c, int D, float* out, csnSt
   CSN_LAUNCH_CHECK();
   return CSN_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Optimiser step of the hot loop on ONE flat parameter / gradient buffer.
+// Replaces: torch.optim.RMSprop(model.parameters(), lr).step() at /root/reference/LstmDistillFromDinoV2Train.py:329,373
+// with that call's defaults (alpha 0.99, eps 1e-8, no momentum, not centred, no weight decay):
+//     v <- alpha v + (1 - alpha) g^2 ;   p <- p - lr g / (sqrt(v) + eps)
+// One pass over 3 x n floats in, 2 x n out (torch's multi-tensor path: five kernels per step).
+namespace csn {
+__global__ void __launch_bounds__(256) rmsprop_flat_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ v,
+                                                          int64_t n, float lr, float alpha, float eps) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t n4 = n >> 2;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    float4 pv = reinterpret_cast<float4*>(p)[i];
+    const float4 gv = reinterpret_cast<const float4*>(g)[i];
+    float4 vv = reinterpret_cast<float4*>(v)[i];
+    vv.x = alpha * vv.x + (1.0f - alpha) * gv.x * gv.x;
+    vv.y = alpha * vv.y + (1.0f - alpha) * gv.y * gv.y;
+    vv.z = alpha * vv.z + (1.0f - alpha) * gv.z * gv.z;
+    vv.w = alpha * vv.w + (1.0f - alpha) * gv.w * gv.w;
+    pv.x -= lr * gv.x / (sqrtf(vv.x) + eps);
+    pv.y -= lr * gv.y / (sqrtf(vv.y) + eps);
+    pv.z -= lr * gv.z / (sqrtf(vv.z) + eps);
+    pv.w -= lr * gv.w / (sqrtf(vv.w) + eps);
+    reinterpret_cast<float4*>(v)[i] = vv;
+    reinterpret_cast<float4*>(p)[i] = pv;
+  }
+  for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float gi = g[i];
+    const float vi = alpha * v[i] + (1.0f - alpha) * gi * gi;
+    v[i] = vi;
+    p[i] -= lr * gi / (sqrtf(vi) + eps);
+  }
+}
+}  // namespace csn
+
+extern "C" int csn_rmsprop_step(float* params, const float* grads, float* square_avg, int64_t n, float lr, float alpha,
+                                float eps, csnStream_t stream) {
+  CSN_REQUIRE(params && grads && square_avg && n > 0, "csn_rmsprop_step: null pointer or empty buffer");
+  CSN_REQUIRE(((reinterpret_cast<uintptr_t>(params) | reinterpret_cast<uintptr_t>(grads) | reinterpret_cast<uintptr_t>(square_avg)) & 15) == 0,
+              "csn_rmsprop_step: buffers must be 16-byte aligned");
+  int64_t blocks = (n / 4 + 255) / 256;
+  if (blocks < 1) blocks = 1;
+  if (blocks > 2048) blocks = 2048;
+  csn::rmsprop_flat_kernel<<<(unsigned)blocks, 256, 0, csn::as_stream(stream)>>>(params, grads, square_avg, n, lr, alpha, eps);
+  CSN_LAUNCH_CHECK();
+  return CSN_OK;
+}

@@ -42,7 +42,9 @@ struct LayerWs {
 };
 struct WsLayout {
   LayerWs layer[8];
-  size_t x_c, x_blk, wih0_blk, dy_tm, tn_scratch, colsum, status, agree, tile_ctr, zeros_bh, total;
+  size_t x_c, x_blk, wih0_blk, dy_tm, tn_scratch, colsum, tn_scratch2, colsum2, status, agree, agree_b, tile_ctr, zeros_bh, total;
+  // weight-stationary paths: everything that must be zero at the start of a forward / a backward sits in ONE block each
+  size_t zero_fwd, zero_fwd_bytes, zero_bwd, zero_bwd_bytes;
   bool fuse_x;
   bool il, persist, persist_bwd;
   bool fwd_ns;             // forward runs the N-split kernel (lstm_fwd_ns.hip), else the K-split one
@@ -75,10 +77,7 @@ static WsLayout make_layout(const csnLstmDesc& d, int training, const Options& o
       L.whht_blk = take(G * H * 2);
       L.hblk[0] = take(Bpad * H * 2);
       L.hblk[1] = take(Bpad * H * 2);
-      if (w.persist) {
-        L.h_blk_all = take(((size_t)d.T + 1) * Bpad * H * 2);
-        L.counters = take(((size_t)d.T + 1) * (Bpad / 64) * kPersistFlagLine * 4);
-      }
+      if (w.persist) L.h_blk_all = take(((size_t)d.T + 1) * Bpad * H * 2);
     } else {
       L.whh = take(G * H * es);
       L.whht = take(G * H * es);
@@ -90,15 +89,12 @@ static WsLayout make_layout(const csnLstmDesc& d, int training, const Options& o
     if (training) {
       L.dgates = take(TB * G * es);
       L.dx = take(TB * I * 4);
-      L.dc_carry = take((size_t)d.B * H * 4);
+      if (!w.persist_bwd) L.dc_carry = take((size_t)d.B * H * 4);
       if (w.il) {
         L.dgblk[0] = take(Bpad * G * 2);
         L.dgblk[1] = take(Bpad * G * 2);
       }
-      if (w.persist_bwd) {
-        L.dg_blk_all = take((size_t)d.T * Bpad * G * 2);
-        L.bflags = take((size_t)d.T * (Bpad / 64) * kPersistFlagLine * 4);
-      }
+      if (w.persist_bwd) L.dg_blk_all = take((size_t)d.T * Bpad * G * 2);
     }
     size_t a = gemm_tn_scratch_bytes(G, I, TB, opt), b = gemm_tn_scratch_bytes(G, H, TB, opt);
     if (a > tn_bytes) tn_bytes = a;
@@ -114,12 +110,30 @@ static WsLayout make_layout(const csnLstmDesc& d, int training, const Options& o
     w.wih0_blk = take(G * d.I * 2);
   }
   if (w.persist_bwd) w.zeros_bh = take((size_t)d.B * H * 4);
-  if (w.persist) w.agree = take(((size_t)d.T + 8) * 8 * sizeof(unsigned long long));   // 8 words per launch
-  if (w.persist) w.tile_ctr = take(((size_t)d.T + 8) * 4 * sizeof(unsigned));          // GEMM tile counters, 4 per launch
+  if (w.persist) {
+    w.zero_fwd = off;
+    for (int l = 0; l < d.L; ++l) w.layer[l].counters = take(((size_t)d.T + 1) * (Bpad / 64) * kPersistFlagLine * 4);
+    w.agree = take(((size_t)d.T + 8) * 8 * sizeof(unsigned long long));   // 8 words per launch
+    w.tile_ctr = take(((size_t)d.T + 8) * 4 * sizeof(unsigned));          // GEMM tile counters, 4 per launch
+    w.zero_fwd_bytes = off - w.zero_fwd;
+  }
+  if (w.persist_bwd) {
+    w.zero_bwd = off;
+    for (int l = 0; l < d.L; ++l) {
+      w.layer[l].dc_carry = take((size_t)d.B * H * 4);
+      w.layer[l].bflags = take((size_t)d.T * (Bpad / 64) * kPersistFlagLine * 4);
+    }
+    w.agree_b = take(((size_t)d.T + 8) * 8 * sizeof(unsigned long long));
+    w.zero_bwd_bytes = off - w.zero_bwd;
+  }
   if (training) {
     w.dy_tm = take(TB * H * 4);
     w.tn_scratch = take(tn_bytes);
     w.colsum = take(colsum_scratch_bytes(G));
+    if (w.persist_bwd && d.L > 1) {     // weight gradients of the upper layers run beside the last backward launches
+      w.tn_scratch2 = take(tn_bytes);
+      w.colsum2 = take(colsum_scratch_bytes(G));
+    }
   }
   w.total = off;
   return w;
@@ -180,6 +194,7 @@ static inline unsigned grid_for(int64_t n) {
 struct SideCtx {
   hipStream_t side = nullptr;           // GEMMs
   hipStream_t layer[8] = {nullptr};     // weight-stationary forward: one stream per layer >= 1
+  hipStream_t wgrad = nullptr;          // LOWEST priority: weight-gradient GEMMs of finished layers beside the last backward launches
   std::vector<hipEvent_t> events;
   size_t next = 0;
 };
@@ -188,6 +203,9 @@ static int side_ctx(SideCtx& c) {
   if (c.side == nullptr) {
     CSN_HIP_CHECK(hipStreamCreateWithFlags(&c.side, hipStreamNonBlocking));
     for (int l = 1; l < 8; ++l) CSN_HIP_CHECK(hipStreamCreateWithFlags(&c.layer[l], hipStreamNonBlocking));
+    int lo = 0, hi = 0;                 // (numerically: lo = least urgent)
+    CSN_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    CSN_HIP_CHECK(hipStreamCreateWithPriority(&c.wgrad, hipStreamNonBlocking, lo));
   }
   c.next = 0;
   return CSN_OK;
@@ -283,6 +301,7 @@ extern "C" void csn_lstm_plan_destroy(csnLstmPlan* P) {
   const bool switched = hipGetDevice(&cur) == hipSuccess && cur != P->device && hipSetDevice(P->device) == hipSuccess;
   for (hipEvent_t e : P->sc.events) (void)hipEventDestroy(e);
   if (P->sc.side) (void)hipStreamDestroy(P->sc.side);
+  if (P->sc.wgrad) (void)hipStreamDestroy(P->sc.wgrad);
   for (int l = 1; l < 8; ++l)
     if (P->sc.layer[l]) (void)hipStreamDestroy(P->sc.layer[l]);
   for (int i = 0; i < 4; ++i)
@@ -331,6 +350,25 @@ extern "C" int csn_lstm_profile_read(csnLstmPlan* P, double* fwd_ms, int* fwd_la
     (k == 0 ? *fwd_launches : *bwd_launches) = g_prof.launches[k];
     (k == 0 ? *fwd_cells : *bwd_cells) = g_prof.cells[k];
   }
+  return CSN_OK;
+}
+
+// Once per workspace, before its first forward: the status word and everything the kernels only ever READ as zero
+// (slot 0 of h_all / c_all of every layer = the zero initial state; the zero row the backward reads where a step has
+// no incoming gradient)
+extern "C" int csn_lstm_workspace_init(const csnLstmPlan* P, void* workspace, csnStream_t stream) {
+  CSN_REQUIRE(P && workspace, "csn_lstm_workspace_init: null pointer");
+  CSN_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 255) == 0, "csn_lstm_workspace_init: workspace must be 256-B aligned");
+  hipStream_t st = as_stream(stream);
+  char* ws = (char*)workspace;
+  const WsLayout& w = P->w;
+  const size_t es = dtype_size(P->d.dtype);
+  CSN_HIP_CHECK(hipMemsetAsync(ws + w.status, 0, 256, st));
+  for (int l = 0; l < P->d.L; ++l) {
+    CSN_HIP_CHECK(hipMemsetAsync(ws + w.layer[l].h_all, 0, (size_t)P->d.B * P->d.H * es, st));
+    CSN_HIP_CHECK(hipMemsetAsync(ws + w.layer[l].c_all, 0, (size_t)P->d.B * P->d.H * 4, st));
+  }
+  if (w.persist_bwd) CSN_HIP_CHECK(hipMemsetAsync(ws + w.zeros_bh, 0, (size_t)P->d.B * P->d.H * 4, st));
   return CSN_OK;
 }
 
@@ -490,8 +528,10 @@ static int forward_il(Plan& P, char* ws, const float* x, int64_t xsb, int64_t xs
       CSN_HIP_CHECK(hipMemsetAsync(ws + L.hblk[0], 0, Bpad * H * 2, st));
       CSN_HIP_CHECK(hipMemsetAsync(ws + L.hblk[1], 0, Bpad * H * 2, st));
     }
-    CSN_HIP_CHECK(hipMemsetAsync(ws + L.h_all, 0, (size_t)B * H * 2, st));
-    CSN_HIP_CHECK(hipMemsetAsync(ws + L.c_all, 0, (size_t)B * H * 4, st));
+    if (!w.persist) {       // (weight-stationary paths: slot 0 is never written, csn_lstm_workspace_init zeroed it)
+      CSN_HIP_CHECK(hipMemsetAsync(ws + L.h_all, 0, (size_t)B * H * 2, st));
+      CSN_HIP_CHECK(hipMemsetAsync(ws + L.c_all, 0, (size_t)B * H * 4, st));
+    }
   }
   if (w.fuse_x) {
     // layer 0 multiplies x_t itself inside the weight-stationary kernel: fragment-major x and W_ih instead of
@@ -582,8 +622,8 @@ static int forward_persist(Plan& P, char* ws, int training, hipStream_t st, Side
   const int Cz = P.opt.chunk;
   const int nch = (T + Cz - 1) / Cz;
   int rc;
-  for (int l = 0; l < NL; ++l)
-    CSN_HIP_CHECK(hipMemsetAsync(ws + w.layer[l].counters, 0, ((size_t)T + 1) * MT * kPersistFlagLine * 4, st));
+  // one fill: the flag lines of every layer, the XCD agreement words, the GEMM tile counters
+  CSN_HIP_CHECK(hipMemsetAsync(ws + w.zero_fwd, 0, w.zero_fwd_bytes, st));
   auto fill_slot = [&](PersistFwdSlot& S, int l, int c) {
     const LayerWs& L = w.layer[l];
     S.w_blk = (const bf16_t*)(ws + L.whh_blk);
@@ -641,8 +681,6 @@ static int forward_persist(Plan& P, char* ws, int training, hipStream_t st, Side
     const int lag = beside ? 2 : 1;
     const int ndiag = nch + lag * (NL - 1);
     const bool try_local = !P.opt.no_xcd_local;
-    if (try_local) CSN_HIP_CHECK(hipMemsetAsync(ws + w.agree, 0, (size_t)ndiag * 8 * sizeof(unsigned long long), st));
-    if (beside) CSN_HIP_CHECK(hipMemsetAsync(ws + w.tile_ctr, 0, (size_t)ndiag * 4 * sizeof(unsigned), st));
     BesideGemm pending[3];
     int npending = 0;
     a.grid_slices = 32;
@@ -898,14 +936,43 @@ static int backward_persist(Plan& P, char* ws, const float* dy_last,
   const int lag = beside ? 2 : 1;
   const int ndiag = nch + lag * (NL - 1);
   int rc;
-  for (int l = 0; l < NL; ++l) {
-    const LayerWs& L = w.layer[l];
-    CSN_HIP_CHECK(hipMemsetAsync(ws + L.dc_carry, 0, (size_t)B * H * 4, st));
-    CSN_HIP_CHECK(hipMemsetAsync(ws + L.bflags, 0, (size_t)T * MT * kPersistFlagLine * 4, st));
-  }
+  // one fill: carried dc and flag lines of every layer, the XCD agreement words (zeros_bh: csn_lstm_workspace_init)
+  CSN_HIP_CHECK(hipMemsetAsync(ws + w.zero_bwd, 0, w.zero_bwd_bytes, st));
   const bool try_local = !P.opt.no_xcd_local;
-  if (try_local) CSN_HIP_CHECK(hipMemsetAsync(ws + w.agree, 0, (size_t)ndiag * 8 * sizeof(unsigned long long), st));
-  CSN_HIP_CHECK(hipMemsetAsync(ws + w.zeros_bh, 0, (size_t)B * H * 4, st));
+
+  // weight / bias gradients of one layer (its recurrence complete): four launches on stream `on`
+  auto weight_grads = [&](int l, hipStream_t on, size_t scratch_off, size_t colsum_off) -> int {
+    const LayerWs& L = w.layer[l];
+    const int64_t I = l == 0 ? d->I : H;
+    const void* inp = l == 0 ? (const void*)(ws + w.x_c)
+                             : (const void*)((const bf16_t*)(ws + w.layer[l - 1].h_all) + (size_t)B * H);
+    float* slabs = (float*)(ws + scratch_off);
+    int S = 1, r;
+    int cs_done = 0, S_cs = 1;
+    if ((r = launch_gemm_tn_slabs(ws + L.dgates, ws + L.h_all, slabs, G, H, TB, CSN_BF16, on, &S, (float*)(ws + colsum_off), &cs_done, P.opt))) return r;
+    S_cs = S;
+    if ((r = launch_reduce_slabs_unperm(slabs, G * H, S, H, H, dw_hh[l], on))) return r;
+    if ((r = launch_gemm_tn_slabs(ws + L.dgates, inp, slabs, G, I, TB, CSN_BF16, on, &S, nullptr, nullptr, P.opt))) return r;
+    if ((r = launch_reduce_slabs_unperm(slabs, G * I, S, H, I, dw_ih[l], on))) return r;
+    // bias gradient = column sums of dgates: partial sums come out of the dW_hh GEMM when its kernel provides them
+    if (!cs_done) {
+      if ((r = launch_colsum_partial(ws + L.dgates, TB, G, CSN_BF16, ws + colsum_off, on))) return r;
+      S_cs = colsum_chunks();
+    }
+    if ((r = launch_reduce_slabs_unperm((const float*)(ws + colsum_off), G, S_cs, H, 1, db_ih[l], on))) return r;
+    CSN_HIP_CHECK(hipMemcpyAsync(db_hh[l], db_ih[l], (size_t)G * 4, hipMemcpyDeviceToDevice, on));
+    return CSN_OK;
+  };
+  // CSN_WGRAD_OVERLAP (off by default -- measured, and worse): an upper layer is done `lag` launches before the
+  // bottom one; its weight-gradient GEMMs can go to a LOWEST-priority stream of the plan right then, to fill the CUs
+  // the last launches leave free (the XCDs of the finished layer's groups + the 8 spare CUs of the others).  On
+  // MI355X the stream priority does not keep the GEMM's workgroups off the CUs the next recurrence launch needs: its
+  // workgroups (one per CU, all of a group resident before anyone advances) wait for GEMM workgroups to retire --
+  // 14.4 vs 11.0 ms per step at cfg2.
+  bool wg_done[8] = {false, false, false, false, false, false, false, false};
+  const bool wg_overlap = NL > 1 && w.tn_scratch2 != 0 && P.opt.wgrad_overlap;
+  bool wg_side = false;
+  if (wg_overlap && (rc = side_ctx(P.sc))) return rc;
 
   PersistBwdArgs a{};
   a.error_flag = (unsigned*)(ws + w.status);
@@ -949,7 +1016,7 @@ static int backward_persist(Plan& P, char* ws, const float* dy_last,
     a.ngemm = npending;
     for (int i = 0; i < npending; ++i) a.gemm[i] = pending[i];
     npending = 0;
-    a.agree = try_local ? (unsigned long long*)(ws + w.agree) + (size_t)dg * 8 : nullptr;
+    a.agree = try_local ? (unsigned long long*)(ws + w.agree_b) + (size_t)dg * 8 : nullptr;
     if ((rc = prof_pair(g_prof, 1, false, st))) return rc;
     if ((rc = launch_bwd_persist(a, st))) return rc;
     if ((rc = prof_pair(g_prof, 1, true, st))) return rc;
@@ -969,6 +1036,16 @@ static int backward_persist(Plan& P, char* ws, const float* dy_last,
         if ((rc = gemm_nt(Ag, ws + L.wiht, nullptr, Cg, Mg, H, G, CSN_BF16, CSN_F32, 0, st, P.opt))) return rc;
       }
     }
+    if (wg_overlap) {
+      for (int i = 0; i < ns; ++i) {
+        const int l = lay[i];
+        if (l == 0 || chk[i] != nch - 1) continue;          // layer l has just walked its last chunk (dgates_l complete)
+        if ((rc = hand_off(&P.sc, st, P.sc.wgrad))) return rc;
+        if ((rc = weight_grads(l, P.sc.wgrad, w.tn_scratch2, w.colsum2))) return rc;
+        wg_done[l] = true;
+        wg_side = true;
+      }
+    }
   }
   if ((rc = prof_mark(g_prof, 3, st))) return rc;
   g_prof.launches[1] = n_launch;
@@ -983,28 +1060,9 @@ static int backward_persist(Plan& P, char* ws, const float* dy_last,
     tb_to_bt_kernel<<<grid_for(TB * d->I), 256, 0, st>>>((const float*)(ws + L.dx), dx, B, T, d->I);
     CSN_LAUNCH_CHECK();
   }
-  for (int l = NL - 1; l >= 0; --l) {
-    const LayerWs& L = w.layer[l];
-    const int64_t I = l == 0 ? d->I : H;
-    const void* inp = l == 0 ? (const void*)(ws + w.x_c)
-                             : (const void*)((const bf16_t*)(ws + w.layer[l - 1].h_all) + (size_t)B * H);
-    float* slabs = (float*)(ws + w.tn_scratch);
-    int S = 1;
-    int cs_done = 0, S_cs = 1;
-    if ((rc = launch_gemm_tn_slabs(ws + L.dgates, ws + L.h_all, slabs, G, H, TB, CSN_BF16, st, &S, (float*)(ws + w.colsum), &cs_done, P.opt))) return rc;
-    S_cs = S;
-    if ((rc = launch_reduce_slabs_unperm(slabs, G * H, S, H, H, dw_hh[l], st))) return rc;
-    if ((rc = launch_gemm_tn_slabs(ws + L.dgates, inp, slabs, G, I, TB, CSN_BF16, st, &S, nullptr, nullptr, P.opt))) return rc;
-    if ((rc = launch_reduce_slabs_unperm(slabs, G * I, S, H, I, dw_ih[l], st))) return rc;
-    // bias gradient = column sums of dgates: partial sums come out of the dW_hh GEMM when its kernel provides them
-    if (!cs_done) {
-      if ((rc = launch_colsum_partial(ws + L.dgates, TB, G, CSN_BF16, ws + w.colsum, st))) return rc;
-      S_cs = colsum_chunks();
-    }
-    if ((rc = launch_reduce_slabs_unperm((const float*)(ws + w.colsum), G, S_cs, H, 1, db_ih[l], st)))
-      return rc;
-    CSN_HIP_CHECK(hipMemcpyAsync(db_hh[l], db_ih[l], (size_t)G * 4, hipMemcpyDeviceToDevice, st));
-  }
+  for (int l = NL - 1; l >= 0; --l)
+    if (!wg_done[l] && (rc = weight_grads(l, st, w.tn_scratch, w.colsum))) return rc;
+  if (wg_side && (rc = hand_off(&P.sc, P.sc.wgrad, st))) return rc;     // the caller's stream resumes after the side work
   return CSN_OK;
 }
 

@@ -30,16 +30,21 @@ def dist_info():
 
 
 class FlatGrads:
-    """All parameter gradients as views into one contiguous float32 buffer."""
+    """All parameter gradients as views into one contiguous float32 buffer; with ``flatten_params`` the parameters
+    themselves too (same offsets), so that an optimiser can step the whole model in one pass."""
 
-    def __init__(self, params):
+    def __init__(self, params, flatten_params=False):
         self.params = [p for p in params if p.requires_grad]
         total = sum(p.numel() for p in self.params)
         self.flat = torch.zeros(total, dtype=torch.float32, device=self.params[0].device)
+        self.flat_params = torch.empty_like(self.flat) if flatten_params else None
         off = 0
         for p in self.params:
             n = p.numel()
             p.grad = self.flat[off:off + n].view_as(p)
+            if flatten_params:
+                self.flat_params[off:off + n].copy_(p.data.reshape(-1))
+                p.data = self.flat_params[off:off + n].view_as(p)
             off += n
 
     def zero(self):
@@ -50,6 +55,34 @@ class FlatGrads:
         if world > 1:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
             self.flat.div_(world)
+
+
+class FlatRMSprop:
+    """``torch.optim.RMSprop(params, lr)`` (LstmDistillFromDinoV2Train.py:329: alpha 0.99, eps 1e-8, no momentum, not
+    centred) as ONE fused HIP pass over the flat parameter / gradient / state buffers of a ``FlatGrads`` (csn_rmsprop_step)
+    instead of torch's five multi-tensor kernels per step.  ``state_dict`` keeps the optimiser resumable."""
+
+    def __init__(self, flat, lr=1e-3, alpha=0.99, eps=1e-8):
+        assert flat.flat_params is not None, "FlatRMSprop needs FlatGrads(..., flatten_params=True)"
+        self.flat, self.lr, self.alpha, self.eps = flat, lr, alpha, eps
+        self.square_avg = torch.zeros_like(flat.flat)
+        self.param_groups = [{"lr": lr, "params": flat.params}]
+
+    @torch.no_grad()
+    def step(self):
+        from . import cabi
+        cabi.rmsprop_step(self.flat.flat_params, self.flat.flat, self.square_avg, self.param_groups[0]["lr"], self.alpha, self.eps)
+
+    def zero_grad(self, set_to_none=False):
+        self.flat.zero()
+
+    def state_dict(self):
+        return {"square_avg": self.square_avg, "lr": self.param_groups[0]["lr"], "alpha": self.alpha, "eps": self.eps}
+
+    def load_state_dict(self, sd):
+        self.square_avg.copy_(sd["square_avg"])
+        self.param_groups[0]["lr"], self.alpha, self.eps = sd["lr"], sd["alpha"], sd["eps"]
+
 
 
 def split_indices(n, fractions=(0.8, 0.2), seed=43):
@@ -99,9 +132,12 @@ class DistillTrainer:
         self.model = model
         self.sos, self.ddof, self.preprocess = sos, ddof, preprocess
         self.loss_name = loss
-        self.grads = FlatGrads(model.parameters())
+        on_gpu = next(model.parameters()).is_cuda
+        self.grads = FlatGrads(model.parameters(), flatten_params=(optimizer == "rmsprop" and on_gpu))
         params = self.grads.params
-        if optimizer == "rmsprop":      # LstmDistillFromDinoV2Train.py:329
+        if optimizer == "rmsprop" and on_gpu:   # LstmDistillFromDinoV2Train.py:329 -- one fused pass over the flat buffers
+            self.opt = FlatRMSprop(self.grads, lr=lr)
+        elif optimizer == "rmsprop":
             self.opt = torch.optim.RMSprop(params, lr=lr)
         elif optimizer == "adamw":      # LstmDistillFromDinoV2TrainSpampinato.py:378
             self.opt = torch.optim.AdamW(params, lr=lr)

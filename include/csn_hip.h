@@ -103,6 +103,11 @@ int csn_lstm_plan_path(const csnLstmPlan* plan);
 /* Same number without a plan (what csn_lstm_plan_workspace_bytes would return for a plan created now). */
 size_t csn_lstm_workspace_bytes(const csnLstmDesc* d, int training);
 
+/* Once per workspace, before its first forward (enqueued on `stream`): zeroes the status word and the regions the
+ * kernels only ever read as zero (the zero initial state h_0 / c_0 of every layer, ...).  A forward / backward
+ * re-zeroes per call only what it dirties (flag lines, carried dc). */
+int csn_lstm_workspace_init(const csnLstmPlan* plan, void* workspace, csnStream_t stream);
+
 /* x: element (b,t,i) at x[b*x_stride_b + t*x_stride_t + i] (float32).
  * w_ih/w_hh/b_ih/b_hh: [host] arrays of L device pointers to float32 parameters
  *   weight_ih_l{k}[4H,I_k], weight_hh_l{k}[4H,H], bias_ih_l{k}[4H], bias_hh_l{k}[4H].
@@ -180,6 +185,15 @@ int csn_lstm_cell_backward(const void* dgates_next, const void* w_hh_t,
  * ---------------------------------------------------------------------------------- */
 int csn_cosine_loss(const float* student, const float* teacher, int B, int D,
                     float* loss, float* dstudent, float grad_scale, csnStream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Optimiser step of the hot loop over ONE flat float32 parameter / gradient / state buffer (16-byte aligned).
+ * Replaces: torch.optim.RMSprop(model.parameters(), lr=...).step(), LstmDistillFromDinoV2Train.py:329,373, with
+ * that call's defaults: square_avg <- alpha square_avg + (1 - alpha) g^2 ; p <- p - lr g / (sqrt(square_avg) + eps)
+ * (alpha 0.99, eps 1e-8; no momentum, not centred, no weight decay).
+ * ---------------------------------------------------------------------------------- */
+int csn_rmsprop_step(float* params, const float* grads, float* square_avg, int64_t n,
+                     float lr, float alpha, float eps, csnStream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * K7  Barlow-Twins reduction over the cross-correlation matrix c[D,D] (float32):

@@ -255,3 +255,31 @@ def test_dino_self_distillation_step_matches_reference_fixture(cuda, golden):
             np.testing.assert_allclose(par.grad.cpu().numpy(), want, atol=1e-4 * max(1e-3, np.abs(want).max()), err_msg=name)
             checked += 1
     assert checked >= 14
+
+
+def test_fused_flat_rmsprop_matches_torch(cuda):
+    """csn_rmsprop_step over the flat buffers = torch.optim.RMSprop(params, lr) (LstmDistillFromDinoV2Train.py:329)
+    for five steps, and the parameters the model sees ARE the flat buffer (views)."""
+    from cerebralsignalnetworks_amd.trainer import FlatGrads, FlatRMSprop
+    torch.manual_seed(3)
+    net = torch.nn.Sequential(torch.nn.Linear(37, 53), torch.nn.Tanh(), torch.nn.Linear(53, 11)).to(cuda)
+    ref = torch.nn.Sequential(torch.nn.Linear(37, 53), torch.nn.Tanh(), torch.nn.Linear(53, 11)).to(cuda)
+    ref.load_state_dict(net.state_dict())
+    fg = FlatGrads(net.parameters(), flatten_params=True)
+    opt = FlatRMSprop(fg, lr=1e-3)
+    ropt = torch.optim.RMSprop(ref.parameters(), lr=1e-3)
+    x = torch.randn(29, 37, device=cuda)
+    for step in range(5):
+        fg.zero()
+        net(x).pow(2).mean().backward()
+        opt.step()
+        ropt.zero_grad()
+        ref(x).pow(2).mean().backward()
+        ropt.step()
+    for (n, p), q in zip(net.named_parameters(), ref.parameters()):
+        assert p.data_ptr() >= fg.flat_params.data_ptr() and p.data_ptr() < fg.flat_params.data_ptr() + fg.flat_params.numel() * 4
+        np.testing.assert_allclose(p.detach().cpu().numpy(), q.detach().cpu().numpy(), rtol=2e-6, atol=1e-7, err_msg=n)
+    sd = opt.state_dict()
+    opt2 = FlatRMSprop(fg, lr=5e-4)
+    opt2.load_state_dict(sd)
+    assert opt2.param_groups[0]["lr"] == 1e-3 and torch.equal(opt2.square_avg, opt.square_avg)

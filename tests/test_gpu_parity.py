@@ -482,9 +482,11 @@ def test_fast_path_matches_oracle_and_v1(cuda, B, T, C, H, L, chunk):
     # the schedules / hand-off forms of the default path compute the same bits: single stream instead of side
     # streams, the placement-independent hand-off instead of the L2-local one
     # (nobeside: the input-gradient GEMMs as kernels of their own between two backward launches, layers one chunk
-    # apart, instead of on the idle workgroups of the next launch with the layers two chunks apart)
+    # apart, instead of on the idle workgroups of the next launch with the layers two chunks apart;
+    # wgrad_beside: the upper layers' weight-gradient GEMMs beside the last backward launches on the plan's
+    # low-priority stream instead of after the recurrence on the caller's stream -- slower, kept as a switch)
     for name, other in (("serial", run(CSN_NO_SIDE_STREAM="1")), ("anyplace", run(CSN_NO_XCD_LOCAL="1")),
-                        ("nobeside", run(CSN_NO_BESIDE="1"))):
+                        ("nobeside", run(CSN_NO_BESIDE="1")), ("wgrad_beside", run(CSN_WGRAD_OVERLAP="1"))):
         for k in fast:
             _assert_same_bits(fast[k], other[k], f"{name}: {k}")
     # with every workgroup walking K in the same order (the default rotates the walk per workgroup, which only
