@@ -512,23 +512,29 @@ static int forward_il(Plan& P, char* ws, const float* x, int64_t xsb, int64_t xs
   const size_t Bpad = ((size_t)B + 63) / 64 * 64;
   const int Cz = P.opt.chunk, lag = 2 * Cz;
 
-  if ((rc = launch_cast_strided(x, xsb, xst, B, T, d->I, ws + w.x_c, CSN_BF16, st))) return rc;
+  // all layout preparation in one launch (prep_multi_kernel)
+  PrepArgs pa{};
+  auto job = [&](int kind, const float* a_, const float* b_, void* dst, int64_t n0, int64_t n1, int64_t n2, int64_t s0,
+                 int64_t s1, int64_t Hh, int pr, int pk, int64_t work) {
+    PrepJob& J = pa.job[pa.njobs++];
+    J = PrepJob{kind, a_, b_, dst, n0, n1, n2, s0, s1, Hh, pr, pk, work, 0u, 0u};
+  };
+  job(kPrepCastX, x, nullptr, ws + w.x_c, B, T, d->I, xsb, xst, 0, 0, 0, TB * d->I);
   for (int l = 0; l < NL; ++l) {
     const LayerWs& L = w.layer[l];
     const int64_t I = l == 0 ? d->I : H;
-    if ((rc = launch_permute_rows_cast(w_ih[l], H, I, ws + L.wih, st))) return rc;
-    if ((rc = launch_blockify(w_hh[l], H, 1, G, H, 1, 0, H, ws + L.whh_blk, st))) return rc;
-    if ((rc = launch_bias_perm_sum(b_ih[l], b_hh[l], H, (float*)(ws + L.bias), st))) return rc;
+    job(kPrepPermRows, w_ih[l], nullptr, ws + L.wih, 0, I, 0, 0, 0, H, 0, 0, G * I);
+    job(kPrepBlockify, w_hh[l], nullptr, ws + L.whh_blk, G, H, 0, H, 1, H, 1, 0, G * H / 8);
+    job(kPrepBias, b_ih[l], b_hh[l], ws + L.bias, 0, 0, 0, 0, 0, H, 0, 0, G);
     if (training) {
-      if ((rc = launch_transpose_perm_cast(w_ih[l], H, I, ws + L.wiht, st))) return rc;
+      job(kPrepTransPerm, w_ih[l], nullptr, ws + L.wiht, 0, I, 0, 0, 0, H, 0, 0, G * I);
       // W_hh^T [H rows = unit][k' = 4u'+g]: element (u, k') = W_hh[std_row(k')][u]
-      if ((rc = launch_blockify(w_hh[l], 1, H, H, G, 0, 1, H, ws + L.whht_blk, st))) return rc;
+      job(kPrepBlockify, w_hh[l], nullptr, ws + L.whht_blk, H, G, 0, 1, H, H, 0, 1, H * G / 8);
     }
     if (!w.persist) {       // ping-pong hand-off buffers of the per-timestep launches
       CSN_HIP_CHECK(hipMemsetAsync(ws + L.hblk[0], 0, Bpad * H * 2, st));
       CSN_HIP_CHECK(hipMemsetAsync(ws + L.hblk[1], 0, Bpad * H * 2, st));
-    }
-    if (!w.persist) {       // (weight-stationary paths: slot 0 is never written, csn_lstm_workspace_init zeroed it)
+      // (weight-stationary paths: slot 0 is never written, csn_lstm_workspace_init zeroed it)
       CSN_HIP_CHECK(hipMemsetAsync(ws + L.h_all, 0, (size_t)B * H * 2, st));
       CSN_HIP_CHECK(hipMemsetAsync(ws + L.c_all, 0, (size_t)B * H * 4, st));
     }
@@ -536,9 +542,11 @@ static int forward_il(Plan& P, char* ws, const float* x, int64_t xsb, int64_t xs
   if (w.fuse_x) {
     // layer 0 multiplies x_t itself inside the weight-stationary kernel: fragment-major x and W_ih instead of
     // a [T, B, 4H] float32 projection written to and re-read from HBM
-    if ((rc = launch_blockify_x(x, xsb, xst, B, T, d->I, ws + w.x_blk, st))) return rc;
-    if ((rc = launch_blockify(w_ih[0], d->I, 1, G, d->I, 1, 0, H, ws + w.wih0_blk, st))) return rc;
-  } else {
+    job(kPrepBlockifyX, x, nullptr, ws + w.x_blk, B, T, d->I, xsb, xst, (int64_t)Bpad, 0, 0, (int64_t)T * Bpad * d->I / 8);
+    job(kPrepBlockify, w_ih[0], nullptr, ws + w.wih0_blk, G, d->I, 0, d->I, 1, H, 1, 0, G * d->I / 8);
+  }
+  if ((rc = launch_prep_multi(pa, st))) return rc;
+  if (!w.fuse_x) {
     // layer 0 input projection for every step, main stream
     if ((rc = gemm_nt(ws + w.x_c, ws + w.layer[0].wih, (const float*)(ws + w.layer[0].bias), ws + w.layer[0].xproj,
                           TB, G, d->I, CSN_BF16, CSN_F32, 0, st, P.opt)))

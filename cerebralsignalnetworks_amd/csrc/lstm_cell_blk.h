@@ -124,6 +124,25 @@ bool bwd_persist_supported(int B, int H, int dtype, const Options& opt);
 int bwd_persist_slices(int H);
 int launch_bwd_persist(const PersistBwdArgs& a, hipStream_t st);
 
+// one launch for all layout-preparation jobs of a forward (lstm_cell_blk.hip: prep_multi_kernel)
+enum { kPrepBlockify = 0, kPrepPermRows, kPrepTransPerm, kPrepBias, kPrepCastX, kPrepBlockifyX };
+static constexpr int kPrepMaxJobs = 32;
+struct PrepJob {
+  int kind;
+  const float* a;
+  const float* b;
+  void* dst;
+  int64_t n0, n1, n2, s0, s1, H;     // meaning per kind (see the kernel)
+  int perm_r, perm_k;
+  int64_t work;                      // work items (threads) of the job
+  unsigned blk_begin, blk_count;     // filled by the launcher
+};
+struct PrepArgs {
+  PrepJob job[kPrepMaxJobs];
+  int njobs;
+};
+int launch_prep_multi(PrepArgs& A, hipStream_t st);
+
 bool cell_blk_supported(int H, int dtype, const Options& opt);
 int launch_cell_fwd_il(const CellFwdArgs& a, int nprob, hipStream_t st, int max_nk);
 int launch_cell_bwd_il(const CellBwdArgs& a, int nprob, hipStream_t st);

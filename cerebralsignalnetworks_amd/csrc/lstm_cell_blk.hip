@@ -113,6 +113,93 @@ __global__ void reduce_slabs_unperm_kernel(const float* __restrict__ slabs, int6
   }
 }
 
+// ---- all layout preparation of a forward in ONE launch ---------------------------------------------------------
+// A training step re-prepares the operands of every layer (the weights change every step): per layer W_ih with
+// interleaved rows, W_hh fragment-major, the summed bias, and for training their transposes; the input in both of its
+// layouts.  As separate kernels that was 13 launches of 5-40 us with a dependent-launch gap behind each (0.15 ms of an
+// 11 ms step); here every job gets a slice of one grid.
+__global__ void __launch_bounds__(256) prep_multi_kernel(PrepArgs A) {
+  int j = 0;
+  while (j + 1 < A.njobs && blockIdx.x >= A.job[j + 1].blk_begin) ++j;
+  const PrepJob& J = A.job[j];
+  const int64_t vb = blockIdx.x - J.blk_begin, vg = J.blk_count;
+  const int64_t gid = vb * blockDim.x + threadIdx.x, stride = vg * blockDim.x;
+  switch (J.kind) {
+    case kPrepBlockify: {                 // fragment-major bf16 image of a (permuted) float32 matrix
+      const int64_t R = J.n0, K = J.n1, H = J.H, ld_r = J.s0, ld_k = J.s1, kblocks = K >> 5;
+      bf16_t* dst = (bf16_t*)J.dst;
+      for (int64_t ci = gid; ci < R * K / 8; ci += stride) {
+        const int64_t blk = ci >> 6, lane = ci & 63;
+        const int64_t r = (blk / kblocks) * 16 + (lane & 15), k = (blk % kblocks) * 32 + 8 * (lane >> 4);
+        const int64_t rs = J.perm_r ? std_row(r, H) : r;
+        bf16x8 v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int64_t ks = J.perm_k ? std_row(k + e, H) : (k + e);
+          v[e] = (bf16_t)J.a[rs * ld_r + ks * ld_k];
+        }
+        *reinterpret_cast<bf16x8*>(dst + ci * 8) = v;
+      }
+      break;
+    }
+    case kPrepPermRows: {                 // dst[n'][i] = src[std_row(n')][i]
+      const int64_t H = J.H, I = J.n1;
+      bf16_t* dst = (bf16_t*)J.dst;
+      for (int64_t i = gid; i < 4 * H * I; i += stride) dst[i] = (bf16_t)J.a[std_row(i / I, H) * I + i % I];
+      break;
+    }
+    case kPrepTransPerm: {                // dst[i][n'] = src[std_row(n')][i]
+      const int64_t H = J.H, I = J.n1, G = 4 * H;
+      bf16_t* dst = (bf16_t*)J.dst;
+      for (int64_t i = gid; i < G * I; i += stride) dst[i] = (bf16_t)J.a[std_row(i % G, H) * I + i / G];
+      break;
+    }
+    case kPrepBias: {                     // dst[n'] = a[std_row(n')] + b[std_row(n')]
+      float* dst = (float*)J.dst;
+      for (int64_t i = gid; i < 4 * J.H; i += stride) dst[i] = J.a[std_row(i, J.H)] + J.b[std_row(i, J.H)];
+      break;
+    }
+    case kPrepCastX: {                    // x[b][t][i] (strides s0, s1) -> time-major [T][B][I] bf16
+      const int64_t Bn = J.n0, Tn = J.n1, I = J.n2;
+      bf16_t* dst = (bf16_t*)J.dst;
+      for (int64_t i = gid; i < Bn * Tn * I; i += stride) {
+        const int64_t i2 = i % I, r = i / I, b = r % Bn, t = r / Bn;
+        dst[i] = (bf16_t)J.a[b * J.s0 + t * J.s1 + i2];
+      }
+      break;
+    }
+    case kPrepBlockifyX: {                // x -> [T][Bpad * I] fragment-major bf16 slabs (rows >= B zero)
+      const int64_t Bn = J.n0, Tn = J.n1, I = J.n2, Bpad = J.H, per_t = Bpad * I / 8, kblocks = I >> 5;
+      bf16_t* dst = (bf16_t*)J.dst;
+      for (int64_t ci = gid; ci < per_t * Tn; ci += stride) {
+        const int64_t t = ci / per_t, c = ci % per_t, blk = c >> 6, lane = c & 63;
+        const int64_t r = (blk / kblocks) * 16 + (lane & 15), k = (blk % kblocks) * 32 + 8 * (lane >> 4);
+        bf16x8 v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (bf16_t)(r < Bn ? J.a[r * J.s0 + t * J.s1 + k + e] : 0.f);
+        *reinterpret_cast<bf16x8*>(dst + ci * 8) = v;
+      }
+      break;
+    }
+  }
+}
+
+int launch_prep_multi(PrepArgs& A, hipStream_t st) {
+  CSN_REQUIRE(A.njobs >= 1 && A.njobs <= kPrepMaxJobs, "launch_prep_multi: %d jobs", A.njobs);
+  unsigned total = 0;
+  for (int j = 0; j < A.njobs; ++j) {
+    int64_t blocks = (A.job[j].work + 255) / 256;      // work = items (threads) of the job
+    if (blocks < 1) blocks = 1;
+    if (blocks > 2048) blocks = 2048;
+    A.job[j].blk_begin = total;
+    A.job[j].blk_count = (unsigned)blocks;
+    total += (unsigned)blocks;
+  }
+  prep_multi_kernel<<<total, 256, 0, st>>>(A);
+  CSN_LAUNCH_CHECK();
+  return CSN_OK;
+}
+
 static inline unsigned cap_grid(int64_t n) {
   int64_t g = (n + 255) / 256;
   return (unsigned)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
