@@ -75,6 +75,7 @@ struct PersistFwdArgs {
   BesideGemm gemm[3];
   int ngemm;
   int grid_slices;
+  int half_tiles;          // K2 x N2 body pipelined over 32-row halves: the flag lines are [T+1][MT][2][line]
   // xcd_groups != 0: 1-D grid of 8 * nslices workgroups; the workgroups that share (blockIdx.x % 8) form one
   // hand-off group (a slot's M-tile) -- under the round-robin dispatch they share an XCD, which each group
   // verifies at run time through agree[group] (zeroed, one set of 8 words per launch) before it uses the

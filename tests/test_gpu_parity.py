@@ -504,8 +504,10 @@ def test_fast_path_matches_oracle_and_v1(cuda, B, T, C, H, L, chunk):
     ns = run(CSN_FWD_NSPLIT="1")
     _assert_same_bits(ns["y_all"], run(CSN_FWD_NSPLIT="1", CSN_PERSIST_STREAMS="1")["y_all"], "ns streams: y_all")
     ns_beside = run(CSN_FWD_NSPLIT="1", CSN_BESIDE_FWD="1")
+    ns_halves = run(CSN_FWD_NSPLIT="1", CSN_FWD_HALVES="1")   # (H = 768: the body pipelined over 32-row halves)
     for k in ns:
         _assert_same_bits(ns[k], ns_beside[k], f"ns beside: {k}")
+        _assert_same_bits(ns[k], ns_halves[k], f"ns halves: {k}")
     ns_bf16x = run(CSN_FWD_NSPLIT="1", CSN_BESIDE_FWD="1", CSN_XPROJ_BF16="1")
     for k in ns:
         assert _rel(ns[k], fast[k]) < 1e-2, (k, _rel(ns[k], fast[k]))
