@@ -112,8 +112,8 @@ static WsLayout make_layout(const csnLstmDesc& d, int training, const Options& o
   if (w.persist_bwd) w.zeros_bh = take((size_t)d.B * H * 4);
   if (w.persist) {
     w.zero_fwd = off;
-    // (x 2: the half-pipelined forward body keeps one flag line per 32-row half)
-    for (int l = 0; l < d.L; ++l) w.layer[l].counters = take(((size_t)d.T + 1) * (Bpad / 64) * 2 * kPersistFlagLine * 4);
+    // (x 4: the wave-specialised forward body keeps one flag line per 16-row chain, the half-pipelined one per 32-row half)
+    for (int l = 0; l < d.L; ++l) w.layer[l].counters = take(((size_t)d.T + 1) * (Bpad / 64) * 4 * kPersistFlagLine * 4);
     w.agree = take(((size_t)d.T + 8) * 8 * sizeof(unsigned long long));   // 8 words per launch
     w.tile_ctr = take(((size_t)d.T + 8) * 4 * sizeof(unsigned));          // GEMM tile counters, 4 per launch
     w.zero_fwd_bytes = off - w.zero_fwd;
@@ -668,12 +668,14 @@ static int forward_persist(Plan& P, char* ws, int training, hipStream_t st, Side
   a.error_flag = (unsigned*)(ws + w.status);
   a.B = B; a.H = H; a.T = T; a.Bpad = Bpad; a.MT = MT;
   a.rotate = !P.opt.no_rotate;
-  a.half_tiles = (w.fwd_ns && H == 768 && P.opt.fwd_halves) ? 1 : 0;
+  a.chains = (w.fwd_ns && H == 768 && P.opt.fwd_ws) ? 4 : 1;
+  a.half_tiles = (w.fwd_ns && H == 768 && P.opt.fwd_halves && a.chains == 1) ? 1 : 0;
   int n_launch = 0;
 
   const int max_slots = NL < nch ? NL : nch;
   const int fwd_slices = w.fwd_ns ? fwd_ns_slices(H) : fwd_persist_slices(H);
   auto launch_fwd = [&](const PersistFwdArgs& args, hipStream_t on) {
+    if (args.chains == 4) return launch_fwd_ws(args, on);
     return w.fwd_ns ? launch_fwd_ns(args, on) : launch_fwd_persist(args, on);
   };
   const bool grouped = max_slots <= 4 && max_slots * MT <= 8 && fwd_slices <= 32 &&

@@ -76,6 +76,7 @@ struct PersistFwdArgs {
   int ngemm;
   int grid_slices;
   int half_tiles;          // K2 x N2 body pipelined over 32-row halves: the flag lines are [T+1][MT][2][line]
+  int chains;              // 4: the wave-specialised body (lstm_fwd_ws.hip), four 16-row chains per tile: flag lines [T+1][MT][4][line]
   // xcd_groups != 0: 1-D grid of 8 * nslices workgroups; the workgroups that share (blockIdx.x % 8) form one
   // hand-off group (a slot's M-tile) -- under the round-robin dispatch they share an XCD, which each group
   // verifies at run time through agree[group] (zeroed, one set of 8 words per launch) before it uses the
@@ -91,6 +92,7 @@ bool fwd_persist_supported(int B, int H, int dtype, const Options& opt);
 bool fwd_ns_supported(int B, int H, int dtype, const Options& opt);
 int fwd_ns_slices(int H);
 int launch_fwd_ns(const PersistFwdArgs& a, hipStream_t st);
+int launch_fwd_ws(const PersistFwdArgs& a, hipStream_t st);   // H = 768, a.chains == 4
 int fwd_persist_slices(int H);   // workgroups per hand-off group
 int launch_fwd_persist(const PersistFwdArgs& a, hipStream_t st);
 

@@ -509,6 +509,15 @@ def test_fast_path_matches_oracle_and_v1(cuda, B, T, C, H, L, chunk):
         _assert_same_bits(ns[k], ns_beside[k], f"ns beside: {k}")
         _assert_same_bits(ns[k], ns_halves[k], f"ns halves: {k}")
     ns_bf16x = run(CSN_FWD_NSPLIT="1", CSN_BESIDE_FWD="1", CSN_XPROJ_BF16="1")
+    if H == 768:
+        # the wave-specialised forward (lstm_fwd_ws.hip): four 16-row chains per tile, MFMA waves + gate waves
+        ws = run(CSN_FWD_WS="1")
+        ws_streams = run(CSN_FWD_WS="1", CSN_PERSIST_STREAMS="1")
+        ws_anyplace = run(CSN_FWD_WS="1", CSN_NO_XCD_LOCAL="1")
+        _assert_same_bits(ws["y_all"], ws_streams["y_all"], "ws streams: y_all")
+        for k in ws:
+            _assert_same_bits(ws[k], ws_anyplace[k], f"ws anyplace: {k}")
+            assert _rel(ws[k], fast[k]) < 1e-2, (k, _rel(ws[k], fast[k]))
     for k in ns:
         assert _rel(ns[k], fast[k]) < 1e-2, (k, _rel(ns[k], fast[k]))
         assert _rel(ns_bf16x[k], fast[k]) < 2e-2, (k, _rel(ns_bf16x[k], fast[k]))
