@@ -9,27 +9,37 @@
 // (kp_recurrence) hid the hand-off latency but not that: 6.0 us of work per step remained.  Here the phases get waves
 // of their own and the 64-row tile is cut into FOUR independent 16-row chains (a chain = one MFMA N-tile of batch rows):
 //
-//   waves 0-3  (one per SIMD)  MFMA waves.  Wave w keeps K-quarter w of the workgroup's 96 gate rows (24 units x
-//              i,f,g,o) in 144 accumulator registers.  Per chain and step: poll the chain's flag line (scalar loads,
-//              a queue of their own), fetch its 16 x 192 slice of h_{t-1} STRAIGHT INTO REGISTERS as six 1 KB operand
-//              fragments (no LDS staging: a K-quarter of a 16-row chain is private to the wave), 36 MFMAs, the six
-//              partial tiles to LDS, bump the chain's LDS counter.  The fetch of the next chain is issued before the
-//              MFMAs of the current one.
-//   waves 4-7  gate waves, one per chain.  Off the critical path: the input part of the pre-activations -- layer 0:
-//              bias + x_t W_ih^T by 24 MFMAs of its own against 96 registers of W_ih; layers above: the projection
-//              read from HBM.  On it: wait for the chain's counter, add the four K-quarter partials, gate math in the
-//              accumulator layout ((i, f, g, o) of one cell in one lane; c stays in registers), a wave-private LDS
-//              transpose, stores with consecutive lanes on consecutive bytes (the h hand-off block first), a COUNTED
-//              vmcnt wait that covers only that first store, the chain's flag.  Then the next step's input request.
+//   waves 4-7  gate waves, one per chain; they own everything of the chain that is latency.  Off the critical path:
+//              the input part of the pre-activations -- layer 0: bias + x_t W_ih^T by 24 MFMAs of its own against 96
+//              registers of W_ih; layers above: the projection read from HBM.  On it: wait for the chain's counter,
+//              add the MFMA waves' tiles, gate math in the accumulator layout ((i, f, g, o) of one cell in one lane;
+//              c stays in registers), a wave-private LDS transpose, stores with consecutive lanes on consecutive
+//              bytes (the h hand-off block first), a COUNTED vmcnt wait that covers only that first store, the
+//              chain's flag.  Then it watches the flag line of the next step (scalar loads), and as soon as all 32
+//              slices have published, brings the chain's 16 x 768 slice of h_t into LDS (24 LDS-DMA pieces of 1 KB
+//              that already have the operand layout; the next input request goes out BEHIND them and a counted wait
+//              covers the pieces only) and posts ready[q].
+//   waves 0-3  (one per SIMD)  MFMA waves: no global memory access at all in the loop.  The 6 gate-row tiles x 2
+//              K-halves of the slice are dealt 3 : 3 : 3 : 3 (wave 0: tile 0 whole + tile 1 lower K-half, wave 1: tile 1
+//              upper half + tile 2 whole, waves 2, 3 the same on tiles 3-5): 36 weight fragments = 144 registers per
+//              wave.  Per chain and step: wait for ready[q] (an LDS read), stream the 24 operand fragments from LDS
+//              (ds_read_b128, four in flight), 36 MFMAs into two accumulators, the two tiles to LDS, bump the chain's
+//              LDS counter.  About 0.35 us per item: the MFMA waves are idle most of the time -- the point is that
+//              no chain ever waits for another chain's memory latency.
 //
-// No workgroup barrier anywhere in the loop: the MFMA waves hear from the gate waves only through the global flags
-// (their own workgroup's among the 32), the gate waves from the MFMA waves through monotonic LDS counters; the partial
-// buffer of a chain cannot be overwritten early because its next MFMAs wait for the flag its own gate wave sets after
-// reading it.  Chains of one workgroup run out of phase, so the MFMA pipes see work while every other latency
-// (flag propagation, fetch, gate math, drain) of the other chains is in flight.
+// No workgroup barrier anywhere in the loop: gate wave -> MFMA waves through ready[q], MFMA waves -> gate wave through
+// the monotonic counter cnt[q]; the h buffer and the tile slots of a chain cannot be overwritten early because each
+// side writes them only after the other has signalled that it is done with the step before.  Chains of one workgroup
+// run out of phase and independently of each other.
 //
-// Registers: 8 waves per CU -> 256 per wave, AGPRs + VGPRs.  MFMA waves: 144 + (24 acc + 2 x 24 operand + addressing);
-// gate waves: 96 + (24 pre-activations + 16 input + 6 c + 16 of partials at a time + math).
+// (First version, measured: MFMA waves K-split 4 ways, each fetching its private K-quarter of the chain straight into
+// registers and polling the flags itself -- 481 us per launch; with the polls moved to the gate waves 356 us: an MFMA
+// wave that waits 1 us for ITS operand blocks the three other chains.  Hence LDS as the meeting point.)
+//
+// Registers: 8 waves per CU -> 256 per wave, which the compiler splits 128 VGPRs : 128 AGPRs.  MFMA waves: 28 weight
+// fragments in AGPRs + 8 in VGPRs (an MFMA takes its A operand from either), 2 accumulators, 4 operand fragments.
+// Gate waves: 96 AGPRs of W_ih + 24 pre-activations + 16-24 input + 6 c + math.
+// LDS: 4 x 24 KB h buffers + 4 x 8 KB tile slots (reused as the chain's transpose area) + 64 B of counters.
 #include "csn_common.h"
 #include "lstm_cell_common.h"
 #include "lstm_cell_blk.h"
@@ -63,11 +73,13 @@ __device__ unsigned long long g_wstamps[16];
 namespace csn {
 
 static constexpr int kWsKB = 24;                                   // k-blocks of H = 768
-static constexpr int kWsKQ = 6;                                    // k-blocks of one K-quarter
 static constexpr int kWsAF = 28;                                   // weight fragments (of 36) kept in AGPRs, the rest in VGPRs
-static constexpr int kWsPartBytes = 4 * 4 * 6144;                  // [chain][K-quarter] six 1 KB partial tiles
+static constexpr int kWsHBuf = kWsKB * 1024;                       // one chain's 16 x 768 slice of h, 24 operand fragments
+static constexpr int kWsSlots = 8 * 1024;                          // one chain's 8 tile slots (f32 16 x 16 tiles); reused as its transpose area
 static constexpr int kWsStageChain = 16 * (208 + 112 + 80);        // gates (bf16 x 4) + c (f32) + h (bf16) of 16 rows x 24 units, padded rows
-static constexpr int kWsLdsBytes = kWsPartBytes + 4 * kWsStageChain + 64;
+static_assert(kWsStageChain <= kWsSlots, "the transpose area lives in the chain's tile slots");
+static constexpr int kWsCtlOff = 4 * kWsHBuf + 4 * kWsSlots;       // cnt[4] | ready[4] | scratch word
+static constexpr int kWsLdsBytes = kWsCtlOff + 64 + 96 * 4;        // + the slice's 96 bias values (fused layer 0)
 
 typedef __attribute__((address_space(3))) unsigned lds_u32;
 
@@ -76,126 +88,97 @@ __device__ __forceinline__ bool ws_error_seen(const PersistFwdArgs& a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// MFMA wave kq: K-quarter kq of all 6 gate-row tiles of the slice, every chain of the tile in turn
-__device__ __forceinline__ void ws_mfma_wave(const PersistFwdArgs& a, const PersistFwdSlot& S, char* smem, int slice,
-                                             int mt, int kq) {
-  constexpr int KB = kWsKB, KQ = kWsKQ;
+// MFMA wave w: one whole gate-row tile + one K-half of the tile it shares with its neighbour, every chain in turn
+template <int odd>
+__device__ __forceinline__ void ws_mfma_wave(const PersistFwdArgs& a, const PersistFwdSlot& S, char* smem, int slice, int w) {
+  constexpr int KB = kWsKB, KH = KB / 2;
   const int lane = threadIdx.x & 63;
-  const int H = a.H, MT = a.MT;
-  const size_t slab = (size_t)a.Bpad * H;
   const int t_first = S.t0, nsteps = S.nsteps;
-  const int rot = a.rotate ? __builtin_amdgcn_readfirstlane((slice * KQ) / (H / 24)) : 0;
+  const int tile_full = 6 * slice + 3 * (w >> 1) + 2 * odd;       // rows of the interleaved 4H axis
+  const int tile_half = 6 * slice + 3 * (w >> 1) + 1;
+  const int kb_half0 = odd * KH;                                   // the K-half of the shared tile this wave multiplies
 
-  // stationary operand: register p holds k-block kq KQ + (p + rot) % KQ of the 6 tiles
-  // (the compiler splits the 256 registers of a wave 128 : 128 between VGPRs and AGPRs: 32 of the 36 fragments live
-  // in AGPRs, 4 in VGPRs -- an MFMA takes its A operand from either)
+  // stationary operand: fragment f < 24 is k-block f of the whole tile, fragment 24 + i k-block kb_half0 + i of the
+  // shared one
   bf16x8 wa[kWsAF], wv[36 - kWsAF];
 #pragma unroll
-  for (int p = 0; p < KQ; ++p) {
-    int kb = p + rot;
-    kb = (kb >= KQ ? kb - KQ : kb) + kq * KQ;
-#pragma unroll
-    for (int j = 0; j < 6; ++j) {
-      const bf16x8 w = *reinterpret_cast<const bf16x8*>(S.w_blk + ((int64_t)(6 * slice + j) * KB + kb) * 512 + lane * 8);
-      if (p * 6 + j < kWsAF) wa[p * 6 + j] = w;
-      else wv[p * 6 + j - kWsAF] = w;
-    }
+  for (int f = 0; f < 36; ++f) {
+    const int tile = f < KB ? tile_full : tile_half;
+    const int kb = f < KB ? f : kb_half0 + (f - KB);
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(S.w_blk + ((int64_t)tile * KB + kb) * 512 + lane * 8);
+    if (f < kWsAF) wa[f] = v;
+    else wv[f - kWsAF] = v;
   }
-  const __amdgpu_buffer_rsrc_t hrsrc =
-      __builtin_amdgcn_make_buffer_rsrc((void*)ns_uniform(S.h_blk_all), 0, __builtin_amdgcn_readfirstlane((int)((size_t)(a.T + 1) * slab * 2)), 0x00020000);
-  lds_u32* const cnt = (lds_u32*)(smem + kWsPartBytes + 4 * kWsStageChain);
-
-  // Is h_{t-1} of chain q complete?  The chain's GATE wave watches the global flag line (it has the time) and posts the
-  // step into ready[q] in LDS: a check costs this wave an LDS read, not an L2 round trip.
+  lds_u32* const cnt = (lds_u32*)(smem + kWsCtlOff);
   lds_u32* const ready = cnt + 4;
+  const unsigned lds_base = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)smem;
+
   auto is_ready = [&](int t, int q) {
     return __builtin_amdgcn_readfirstlane((int)__hip_atomic_load(ready + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) >= t;
   };
-  auto wait_ready = [&](int t, int q) {
-    const unsigned long long t_begin = wall_clock64();
-    while (!is_ready(t, q)) {
-      __builtin_amdgcn_s_sleep(1);
-      if (wall_clock64() - t_begin > 2 * kNsSpinTimeoutTicks) {       // (the gate waves bound their own polls; this only ends a lost wave)
-        __hip_atomic_store(a.error_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        break;
-      }
-    }
-  };
-  // One operand buffer: the fragment of k-block p is re-requested for the NEXT item right behind the 6 MFMAs that
-  // read it for the current one (the 128 VGPRs of a wave do not hold two buffers beside the accumulators and the
-  // weight fragments that do not fit the AGPRs) -- so the next item's flag is polled before the current MFMAs start.
-  bf16x8 hf[KQ];
-  auto hoff_of = [&](int t, int q) {
-    return __builtin_amdgcn_readfirstlane((int)(((size_t)t * slab + ((size_t)(mt * 4 + q) * KB + kq * KQ) * 512) * 2));
-  };
-  auto load_block = [&](int p, int sbase) {
-    int kb = p + rot;
-    kb = kb >= KQ ? kb - KQ : kb;
-    hf[p] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(hrsrc, lane * 16, sbase + kb * 1024, 16));   // sc1: hand-off data
-  };
-  auto mfma_block = [&](f32x4 (&acc)[6], int p) {
-#pragma unroll
-    for (int j = 0; j < 6; ++j) {
-      if (p * 6 + j < kWsAF) ns_mfma<false>(acc[j], wa[p * 6 + j], hf[p]);
-      else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[j]) : "v"(wv[p * 6 + j - kWsAF]), "v"(hf[p]));
-    }
+  // (first: the accumulator starts from the literal 0 -- no register initialisation that would have to be kept, with
+  // wait states the hazard recogniser cannot see are needed, in front of an inline-asm MFMA)
+  auto mfma_frag = [&](f32x4& acc, int f, const bf16x8& h, bool first) {
+    static_assert(kWsAF > kWsKB, "the first fragment of either tile lives in AGPRs");
+    if (first) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(acc) : "a"(wa[f]), "v"(h));
+    else if (f < kWsAF) ns_mfma<false>(acc, wa[f], h);
+    else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(wv[f - kWsAF]), "v"(h));
   };
 
   const int N = 4 * nsteps;
-  CSN_WSTAMP_INIT(kq == 0);
-  if (t_first > 0) {
-    wait_ready(t_first, 0);
-    const int sb = hoff_of(t_first, 0);
-#pragma unroll
-    for (int p = 0; p < KQ; ++p) load_block(p, sb);
-  }
+  CSN_WSTAMP_INIT(w == 0);
   for (int i = 0; i < N; ++i) {
     const int t = t_first + (i >> 2), q = i & 3;
-    const int tn = t_first + ((i + 1) >> 2), qn = (i + 1) & 3;
-    const bool next_valid = i + 1 < N && tn > 0;
-    const int sbn = hoff_of(tn, qn);
-    // the next item's operand is requested between the MFMAs of this one if its chain is ready NOW; otherwise after
-    // them, in one go, as soon as it is
-    bool requested = false;
     if (t > 0) {
-      f32x4 acc[6];
-#pragma unroll
-      for (int j = 0; j < 6; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      ns_wait_vmcnt<0>();
-      CSN_WSTAMP(1);   // operand fragments of the current item
-      __builtin_amdgcn_sched_barrier(0);
-      ns_mfma_fence();
-      if (next_valid && is_ready(tn, qn)) {
-        requested = true;
-#pragma unroll
-        for (int p = 0; p < KQ; ++p) {
-          mfma_block(acc, p);
-          __builtin_amdgcn_sched_barrier(0);
-          load_block(p, sbn);
-          __builtin_amdgcn_sched_barrier(0);
+      // ---- h_{t-1} of the chain is in LDS (its gate wave posts the step)
+      {
+        const unsigned long long t_begin = wall_clock64();
+        while (!is_ready(t, q)) {
+          __builtin_amdgcn_s_sleep(1);
+          if (wall_clock64() - t_begin > 2 * kNsSpinTimeoutTicks) {     // (the gate waves bound their own polls; this only ends a lost wave)
+            __hip_atomic_store(a.error_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+          }
         }
-      } else {
-#pragma unroll
-        for (int p = 0; p < KQ; ++p) mfma_block(acc, p);
       }
-      ns_mfma_fence();
-      CSN_WSTAMP(2);   // MFMAs + requests
-      __builtin_amdgcn_sched_barrier(0);
-      f32x4* const part = reinterpret_cast<f32x4*>(smem + (size_t)(q * 4 + kq) * 6144);
+      CSN_WSTAMP(0);   // waiting for the chain
+      unsigned zero_;
+      asm volatile("v_mov_b32 %0, 0" : "=v"(zero_));
+      const unsigned hb = lds_base + (unsigned)(q * kWsHBuf) + (unsigned)lane * 16u + zero_;
+      f32x4 acc_full, acc_half;
+      bf16x8 hf[4];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-      for (int j = 0; j < 6; ++j) part[j * 64 + lane] = acc[j];
+      for (int d = 0; d < 4; ++d) hf[d] = ns_lds_read_b128(hb + (unsigned)(d * 1024));
+      ns_mfma_fence();
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) {
+        const int behind = KB - 1 - kb < 3 ? KB - 1 - kb : 3;         // reads issued after the one this k-block needs
+        if (behind == 3) asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
+        else if (behind == 2) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+        else if (behind == 1) asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory");
+        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_frag(acc_full, kb, hf[kb & 3], kb == 0);
+        if (odd ? kb >= KH : kb < KH) mfma_frag(acc_half, KB + (odd ? kb - KH : kb), hf[kb & 3], kb == (odd ? KH : 0));
+        __builtin_amdgcn_sched_barrier(0);
+        if (kb + 4 < KB) hf[kb & 3] = ns_lds_read_b128(hb + (unsigned)((kb + 4) * 1024));
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // (the wait states between the last MFMA and the first read of its result, tied to the registers so that no
+      // use can be scheduled in front of them)
+      asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc_full), "+v"(acc_half));
+      CSN_WSTAMP(1);   // LDS reads + MFMAs
+      __builtin_amdgcn_sched_barrier(0);
+      // slots of the chain: wave 0 -> 0 (tile 0), 1 (tile 1 lower); wave 1 -> 2 (tile 1 upper), 3 (tile 2); waves 2, 3 -> 4..7
+      f32x4* const slot = reinterpret_cast<f32x4*>(smem + 4 * kWsHBuf + (size_t)q * kWsSlots) + (size_t)(2 * w) * 64 + lane;
+      slot[odd ? 64 : 0] = acc_full;
+      slot[odd ? 0 : 64] = acc_half;
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (lane == 0) __hip_atomic_fetch_add(cnt + q, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     __builtin_amdgcn_sched_barrier(0);
-    CSN_WSTAMP(3);     // partials to LDS + counter
-    if (next_valid && !requested) {
-      wait_ready(tn, qn);
-      CSN_WSTAMP(0);   // waiting for the next chain
-#pragma unroll
-      for (int p = 0; p < KQ; ++p) load_block(p, sbn);
-    }
-    __builtin_amdgcn_sched_barrier(0);
+    CSN_WSTAMP(2);     // tiles to LDS + counter
   }
 }
 
@@ -217,13 +200,13 @@ __device__ __forceinline__ void ws_gate_wave(const PersistFwdArgs& a, const Pers
   const size_t flag_step = (size_t)MT * 4 * kPersistFlagLine;
   const int t_first = S.t0, nsteps = S.nsteps;
   const bool full = r0 + 16 <= B;                      // every row of the chain is a real batch row
-  char* const sg = smem + kWsPartBytes + (size_t)q * kWsStageChain;   // gates [16 rows][208 B]: 24 units x (i, f, g, o) bf16
+  char* const hbuf = smem + (size_t)q * kWsHBuf;                       // the chain's slice of h_{t-1}: 24 operand fragments
+  char* const slots = smem + 4 * kWsHBuf + (size_t)q * kWsSlots;       // the MFMA waves' 8 tiles; then this wave's transpose area:
+  char* const sg = slots;                                              // gates [16 rows][208 B]: 24 units x (i, f, g, o) bf16
   char* const sc = sg + 16 * 208;                                      // c     [16 rows][112 B]: 24 units f32
   char* const sh = sc + 16 * 112;                                      // h     [16 rows][ 80 B]: 24 units bf16
-  lds_u32* const cnt = (lds_u32*)(smem + kWsPartBytes + 4 * kWsStageChain);
+  lds_u32* const cnt = (lds_u32*)(smem + kWsCtlOff);
   lds_u32* const ready = cnt + 4;
-  // (a chunk that does not start the sequence: everything before it was published by launches that have completed)
-  if (t_first > 0 && lane == 0) __hip_atomic_store(ready + q, (unsigned)t_first, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 
   // the 6 cells of this lane: row r0 + (lane & 15), units u0 + 4 j + (lane >> 4)
   const int unit_q = u0 + (lane >> 4);
@@ -234,16 +217,13 @@ __device__ __forceinline__ void ws_gate_wave(const PersistFwdArgs& a, const Pers
   for (int j = 0; j < 6; ++j) cst[j] = t_first > 0 ? c_all[((size_t)t_first * B + rowc) * H + unit_q + 4 * j] : 0.0f;
 
   bf16x8 wih[FUSED ? xkb : 1][6];
-  f32x4 biasv[6];
+  const float* const lds_bias = reinterpret_cast<const float*>(smem + kWsCtlOff + 64);   // (written by the kernel prologue)
   if constexpr (FUSED) {
 #pragma unroll
     for (int kb = 0; kb < xkb; ++kb)
 #pragma unroll
       for (int j = 0; j < 6; ++j)
         wih[kb][j] = *reinterpret_cast<const bf16x8*>(S.wih_blk + ((int64_t)(6 * slice + j) * xkb + kb) * 512 + lane * 8);
-#pragma unroll
-    for (int j = 0; j < 6; ++j)
-      biasv[j] = *reinterpret_cast<const f32x4*>(S.bias + 16 * (size_t)(6 * slice + j) + 4 * (lane >> 4));
   }
 
   f32x4 nxt[P];
@@ -263,10 +243,29 @@ __device__ __forceinline__ void ws_gate_wave(const PersistFwdArgs& a, const Pers
       for (int j = 0; j < 6; ++j) nxt[j] = ns_bload_nt_f32x4(in_rsrc, xvoff + j * 64, sbase);
     }
   };
-  request_input(t_first);
 
   const __amdgpu_buffer_rsrc_t hdst_rsrc =
       __builtin_amdgcn_make_buffer_rsrc((void*)ns_uniform(S.h_blk_all), 0, __builtin_amdgcn_readfirstlane((int)((size_t)(a.T + 1) * slab * 2)), 0x00020000);
+  // h_{t-1} of the chain (slab t, row group 4 mt + q: 24 contiguous 1 KB fragments) -> LDS, then the input of step t
+  // BEHIND it; the counted wait covers the 24 pieces only (vmcnt counts in issue order), then the MFMA waves may start
+  auto fetch_and_post = [&](int t) {
+    const int sbase = __builtin_amdgcn_readfirstlane((int)(((size_t)t * slab + (size_t)(mt * 4 + q) * kWsKB * 512) * 2));
+#pragma unroll
+    for (int kb = 0; kb < kWsKB; ++kb) ns_dma16_sc1(hdst_rsrc, hbuf + kb * 1024, lane * 16, sbase + kb * 1024);
+    __builtin_amdgcn_sched_barrier(0);
+    request_input(t);
+    __builtin_amdgcn_sched_barrier(0);
+    ns_wait_vmcnt<P>();
+    __builtin_amdgcn_sched_barrier(0);
+#ifndef CSN_WS_NO_SETTLE
+    __builtin_amdgcn_s_sleep(4);
+#endif
+    __builtin_amdgcn_sched_barrier(0);
+    if (lane == 0) __hip_atomic_store(ready + q, (unsigned)t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  };
+  // (a chunk that does not start the sequence: everything before it was published by launches that have completed)
+  if (t_first > 0) fetch_and_post(t_first);
+  else request_input(t_first);
 
   CSN_WSTAMP_INIT(q == 0);
 #ifdef CSN_PSTAMPS
@@ -276,19 +275,18 @@ __device__ __forceinline__ void ws_gate_wave(const PersistFwdArgs& a, const Pers
     const int t = t_first + s;
     // ---- input part of the pre-activations (nothing here depends on h_{t-1})
     f32x4 pre[6];
-    CSN_WSTAMP(14);    // input request
     ns_wait_vmcnt<0>();
     CSN_WSTAMP(8);     // input arrives (and every store of the step before has landed)
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (FUSED) {
 #pragma unroll
-      for (int j = 0; j < 6; ++j) pre[j] = biasv[j];
+      for (int j = 0; j < 6; ++j) pre[j] = *reinterpret_cast<const f32x4*>(lds_bias + 16 * j + 4 * (lane >> 4));
       ns_mfma_fence();
 #pragma unroll
       for (int kb = 0; kb < xkb; ++kb)
 #pragma unroll
         for (int j = 0; j < 6; ++j) ns_mfma<false>(pre[j], wih[kb][j], __builtin_bit_cast(bf16x8, nxt[kb]));
-      ns_mfma_fence();
+      asm volatile("s_nop 15\n\ts_nop 7" : "+v"(pre[0]), "+v"(pre[1]), "+v"(pre[2]), "+v"(pre[3]), "+v"(pre[4]), "+v"(pre[5]));
     } else {
 #pragma unroll
       for (int j = 0; j < 6; ++j) pre[j] = nxt[j];
@@ -296,7 +294,7 @@ __device__ __forceinline__ void ws_gate_wave(const PersistFwdArgs& a, const Pers
     __builtin_amdgcn_sched_barrier(0);
 
     CSN_WSTAMP(9);     // x MFMAs
-    // ---- the four K-quarter partials of this chain and step
+    // ---- the MFMA waves' tiles of this chain and step
     {
       const unsigned want = 4u * (unsigned)(s + 1);
       const unsigned long long t_begin = wall_clock64();
@@ -308,14 +306,17 @@ __device__ __forceinline__ void ws_gate_wave(const PersistFwdArgs& a, const Pers
         }
       }
     }
-    CSN_WSTAMP(10);    // wait for the partials
+    CSN_WSTAMP(10);    // wait for the tiles
     if (t > 0) {
-#pragma unroll
-      for (int j = 0; j < 6; ++j) {
-        const f32x4* const part = reinterpret_cast<const f32x4*>(smem + (size_t)(q * 4) * 6144) + j * 64 + lane;
-        const f32x4 p0 = part[0], p1 = part[6144 / 16], p2 = part[2 * 6144 / 16], p3 = part[3 * 6144 / 16];
-        pre[j] = pre[j] + ((p0 + p1) + (p2 + p3));
-      }
+      // slots: 0 tile 0 | 1, 2 the K-halves of tile 1 | 3 tile 2 | 4 tile 3 | 5, 6 the K-halves of tile 4 | 7 tile 5
+      const f32x4* const sl = reinterpret_cast<const f32x4*>(slots) + lane;
+      const f32x4 s0 = sl[0], s1 = sl[64], s2 = sl[128], s3 = sl[192], s4 = sl[256], s5 = sl[320], s6 = sl[384], s7 = sl[448];
+      pre[0] = pre[0] + s0;
+      pre[1] = pre[1] + (s1 + s2);
+      pre[2] = pre[2] + s3;
+      pre[3] = pre[3] + s4;
+      pre[4] = pre[4] + (s5 + s6);
+      pre[5] = pre[5] + s7;
     }
     // ---- gate math in place; results into the wave's transpose area
 #pragma unroll
@@ -379,9 +380,7 @@ __device__ __forceinline__ void ws_gate_wave(const PersistFwdArgs& a, const Pers
       else __hip_atomic_store(fl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __builtin_amdgcn_sched_barrier(0);
-    request_input(s + 1 < nsteps ? t + 1 : t);
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- watch the chain's flag line for the MFMA waves: all 32 slices have published rows 16 q .. 16 q + 15 of h_t
+    // ---- watch the chain's flag line: once all 32 slices have published rows 16 q .. 16 q + 15 of h_t, bring them in
     if (s + 1 < nsteps) {
       const unsigned* line = ns_uniform(flags + (size_t)(t + 1) * flag_step);
       const unsigned long long t_begin = wall_clock64();
@@ -393,8 +392,9 @@ __device__ __forceinline__ void ws_gate_wave(const PersistFwdArgs& a, const Pers
         }
         if (waited > 2000ull && ws_error_seen(a)) break;     // (after 20 us of waiting: has someone else given up?)
       }
-      if (lane == 0) __hip_atomic_store(ready + q, (unsigned)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       CSN_WSTAMP(15);  // flag line of the next step complete
+      fetch_and_post(t + 1);
+      CSN_WSTAMP(14);  // h tile into LDS
     }
   }
 #ifdef CSN_PSTAMPS
@@ -426,9 +426,13 @@ __global__ void __launch_bounds__(512) lstm_fwd_ws_kernel(PersistFwdArgs a) {
   const int mt = grp % MT;
 
   // ---- is this group on one XCD?  (lstm_fwd_persist.hip)
-  int* const shared_word = reinterpret_cast<int*>(smem + kWsPartBytes + 4 * kWsStageChain + 32);
-  lds_u32* const cnt = (lds_u32*)(smem + kWsPartBytes + 4 * kWsStageChain);
-  if (tid < 8) cnt[tid] = 0u;                          // 4 partial counters + 4 ready words
+  int* const shared_word = reinterpret_cast<int*>(smem + kWsCtlOff + 32);
+  lds_u32* const cnt = (lds_u32*)(smem + kWsCtlOff);
+  if (tid < 8) cnt[tid] = 0u;                          // 4 tile counters + 4 ready words
+  if constexpr (FUSE) {
+    if (S.x_blk != nullptr && tid >= 64 && tid < 160)
+      reinterpret_cast<float*>(smem + kWsCtlOff + 64)[tid - 64] = S.bias[96 * (size_t)slice + (tid - 64)];
+  }
   bool local = false;
   if (a.xcd_groups && a.agree != nullptr) {
     if (tid == 0) {
@@ -455,7 +459,8 @@ __global__ void __launch_bounds__(512) lstm_fwd_ws_kernel(PersistFwdArgs a) {
 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   if (wave < 4) {
-    ws_mfma_wave(a, S, smem, slice, mt, wave);
+    if (wave & 1) ws_mfma_wave<1>(a, S, smem, slice, wave);
+    else ws_mfma_wave<0>(a, S, smem, slice, wave);
     return;
   }
   if constexpr (FUSE) {

@@ -25,11 +25,11 @@ for it in range(4):
     lib.csn_debug_read_wstamps(buf)
     if sum(buf) != 0:
         w = [buf[i] * 0.01 / T for i in range(16)]
-        print("step %d fwd-ws per-step us, MFMA wave 0 (4 chains): poll next %.2f | operand wait %.2f | mfma+requests %.2f | lds write+bump %.2f | sum %.2f"
-              % (it, w[0], w[1], w[2], w[3], sum(w[:4])))
-        print("          gate wave 0 (chain 0): input wait %.2f | x mfma %.2f | wait partials %.2f | sum+gate math %.2f | stores %.2f | drain %.2f | flag+request %.2f | sum %.2f"
-              % (w[8], w[9], w[10], w[11], w[12], w[13], w[14], sum(w[8:15])), flush=True)
-        print("          watching the next flag line %.2f | shader clock during the chunk: %.0f MHz" % (w[15], 100.0 * buf[5] / max(buf[6], 1)), flush=True)
+        print("step %d fwd-ws per-step us, MFMA wave 0 (4 chains): wait ready %.2f | lds reads + mfma %.2f | tiles to lds + bump %.2f | sum %.2f"
+              % (it, w[0], w[1], w[2], sum(w[:3])))
+        print("          gate wave 0 (chain 0): input wait %.2f | x mfma %.2f | wait tiles %.2f | sum+gate math %.2f | stores %.2f | drain %.2f | flag + watch next line %.2f | h tile to LDS %.2f | sum %.2f"
+              % (w[8], w[9], w[10], w[11], w[12], w[13], w[15], w[14], sum(w[8:16])), flush=True)
+        print("          shader clock during the chunk: %.0f MHz" % (100.0 * buf[5] / max(buf[6], 1)), flush=True)
     for name, fn in (("fwd-ksplit", lib.csn_debug_read_pstamps), ("fwd-nsplit", lib.csn_debug_read_nstamps),
                      ("bwd", lib.csn_debug_read_bstamps)):
         fn(buf)
