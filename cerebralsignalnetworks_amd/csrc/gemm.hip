@@ -598,19 +598,36 @@ gemm_nt_256_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ Bt, 
     }
   }
 
+  // ---- epilogue through LDS: in the accumulator layout a wave's store instruction covers 16 rows x 64 bytes (16 half
+  // cache lines); staged as a [256][128] f32 image in the ring's memory, every store instruction writes two full
+  // 512-byte rows of the tile
+  constexpr int LDC = 132;                    // padded row (floats): the 16 rows of a fragment column fall in 16 distinct bank groups
+  static_assert(256 * LDC * 4 <= NSTAGE * 49152, "the C image lives in the staging ring");
+  float* const cs = reinterpret_cast<float*>(smem);
+  __syncthreads();                            // (every DMA has landed: the last k-step waited vmcnt(0)) all waves have left the ring
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int64_t m = m0 + wm * 64 + i * 16 + (lane & 15);
-    if (m >= M) continue;
+  for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int64_t n = n0 + wn * 64 + j * 16 + (lane >> 4) * 4;
-      if (n + 3 < N) {
-        f32x4 v = acc[i][j];
-        if (bias) {
-          const float4 bz = *reinterpret_cast<const float4*>(bias + n);
-          v[0] += bz.x; v[1] += bz.y; v[2] += bz.z; v[3] += bz.w;
-        }
+    for (int j = 0; j < 4; ++j)
+      *reinterpret_cast<f32x4*>(cs + (wm * 64 + i * 16 + (lane & 15)) * LDC + wn * 64 + j * 16 + (lane >> 4) * 4) = acc[i][j];
+  __syncthreads();
+  {
+    const int c4 = tid & 31, r0 = tid >> 5;
+    const int64_t n = n0 + c4 * 4;
+    const bool vec = n + 3 < N;
+    f32x4 bz = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (bias) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (n + r < N) bz[r] = bias[n + r];
+    }
+#pragma unroll 4
+    for (int pass = 0; pass < 16; ++pass) {
+      const int row = pass * 16 + r0;
+      const int64_t m = m0 + row;
+      if (m >= M) continue;
+      f32x4 v = *reinterpret_cast<const f32x4*>(cs + row * LDC + c4 * 4) + bz;
+      if (vec) {
         if constexpr (sizeof(OutT) == 4) {
           float4* dst = reinterpret_cast<float4*>((float*)C + m * N + n);
           if (accumulate) { const float4 o = *dst; v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w; }
@@ -622,12 +639,11 @@ gemm_nt_256_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ Bt, 
       } else {
         for (int r = 0; r < 4; ++r)
           if (n + r < N) {
-            float v = acc[i][j][r] + (bias ? bias[n + r] : 0.f);
             if constexpr (sizeof(OutT) == 4) {
               float* dst = (float*)C + m * N + n + r;
-              *dst = accumulate ? *dst + v : v;
+              *dst = accumulate ? *dst + v[r] : v[r];
             } else {
-              ((bf16_t*)C)[m * N + n + r] = (bf16_t)v;
+              ((bf16_t*)C)[m * N + n + r] = (bf16_t)v[r];
             }
           }
       }
