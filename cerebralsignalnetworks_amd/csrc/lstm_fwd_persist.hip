@@ -102,6 +102,9 @@ __device__ __forceinline__ T bounded_poll(const T* p, unsigned* error_flag, Pred
   return v;
 }
 
+#ifndef CSN_FWD_RING
+#define CSN_FWD_RING 4
+#endif
 template <int NQ, int KS>
 __global__ void __launch_bounds__(256) lstm_fwd_persist_kernel(PersistFwdArgs a) {
   constexpr int NT = 4 * NQ;
@@ -294,7 +297,7 @@ __global__ void __launch_bounds__(256) lstm_fwd_persist_kernel(PersistFwdArgs a)
       const int base = (int)(((size_t)t * slab + ((size_t)(m0 >> 4) * kblocks + ks_beg) * 512 + lane * 8) * 2);
       // issue order = consumption order (k-step major), pinned, so the MFMAs of k-step ks wait only for its
       // own 4 loads (counted vmcnt) while the younger ones are still in flight
-      constexpr int RING = KS > 4 ? 4 : KS;      // k-blocks of h in flight per wave (registers)
+      constexpr int RING = KS > CSN_FWD_RING ? CSN_FWD_RING : KS;      // k-blocks of h in flight per wave (registers)
       bf16x8 hf[RING][4];
 #pragma unroll
       for (int ks = 0; ks < RING; ++ks) {
