@@ -283,3 +283,31 @@ def test_fused_flat_rmsprop_matches_torch(cuda):
     opt2 = FlatRMSprop(fg, lr=5e-4)
     opt2.load_state_dict(sd)
     assert opt2.param_groups[0]["lr"] == 1e-3 and torch.equal(opt2.square_avg, opt.square_avg)
+
+
+def test_bench_line_schema(cuda):
+    """bench.py's contract with the driver: ONE JSON line on stdout with the metric of BASELINE.json, the roofline
+    object of the dominant kernel (measured with HIP events inside the run) and no model keys in `config`."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1",
+                          "--no-cpu-baseline", "--no-retrieval", "--no-f32-line"],
+                         capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in d, k
+    assert d["unit"] == "segments/s" and d["n_gpus"] == 1 and d["steps"] == 2 and d["scaling"] == "weak"
+    assert d["vs_baseline"] is None and d["dtype"] == "bf16" and d["data"] == "synthetic"
+    assert d["config"]["workload"].startswith("cfg2") and "model" not in d["config"]
+    assert abs(d["value"] - 256 * 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0.0 < r["frac"] < 1.0
+    assert r["us_per_launch"]["fwd"] > 0 and r["us_per_launch"]["bwd"] > 0
