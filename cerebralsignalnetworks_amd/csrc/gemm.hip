@@ -627,6 +627,9 @@ gemm_nt_256_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ Bt, 
       const int64_t m = m0 + row;
       if (m >= M) continue;
       f32x4 v = *reinterpret_cast<const f32x4*>(cs + row * LDC + c4 * 4) + bz;
+#if defined(CSN_NT_ABL) && CSN_NT_ABL == 1     // (ablation, timing only: no C stores unless a value is NaN)
+      if (v[0] == v[0]) continue;
+#endif
       if (vec) {
         if constexpr (sizeof(OutT) == 4) {
           float4* dst = reinterpret_cast<float4*>((float*)C + m * N + n);
@@ -686,7 +689,7 @@ __device__ __forceinline__ bf16x8 tr_read_pair(unsigned addr) {
   return u.b;
 }
 
-template <int NSTAGE, bool COLSUM>
+template <int NSTAGE, bool COLSUM, bool STAGGER = false>
 __global__ void __launch_bounds__(512)
 gemm_tn_256_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ Bm, float* __restrict__ slabs,
                    int64_t M, int64_t N, int64_t K, int64_t k_per_split, float* __restrict__ colsum) {
@@ -755,6 +758,72 @@ gemm_tn_256_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ Bm, 
     for (int j = 0; j < 4; ++j) b_addr[j] = (unsigned)tn256_lds_off(8 * g + q, wn * 64 + j * 16 + 4 * pp);
   }
 
+  if constexpr (STAGGER) {
+    // Two wave groups (waves 0-3 / 4-7: one wave of each per SIMD) run the same k-steps ONE BARRIER INTERVAL apart: a
+    // k-step is  A = {retire stage h+1, request stage h+3, issue the 24 fragment reads of stage h} | barrier |
+    // B = {32 MFMAs} | barrier,  so while one group's waves multiply, the other group's waves on the same SIMDs issue
+    // their DMA pieces and LDS reads (with one common phase per k-step both waves of a SIMD want the MFMA pipe, then
+    // the LDS pipe, at the same time: MFMA busy 48 %).  Intervals I_n between barriers n and n+1: the leading group
+    // does A_h in I_2h, B_h in I_2h+1, the lagging group A_h in I_2h+1, B_h in I_2h+2.
+    //   read-after-DMA : a wave retires ITS pieces of stage s at the start of its A_(s-1) (counted vmcnt), i.e. before
+    //                    barrier 2s-1 (leading) / 2s (lagging); the first read of stage s is in I_2s.
+    //   DMA-after-read : the last reads of stage h retire inside the lagging group's B_h (I_2h+2); its slot takes
+    //                    stage h+5, requested in A_(h+2) = I_2h+4 / I_2h+5.  Hence 5 stages, prefetch distance 3.
+    static_assert(!STAGGER || NSTAGE == 5, "staggered form: ring of 5 stages");
+    const int grp = __builtin_amdgcn_readfirstlane(wave >> 2);
+#pragma unroll
+    for (int h = 0; h < 3; ++h)
+      if (h < nh) issue(h);
+    if (nh >= 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (nh == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (grp == 1) __builtin_amdgcn_s_barrier();
+    for (int h = 0; h < nh; ++h) {
+      if (h + 2 < nh) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#if !defined(CSN_TN_ABL) || CSN_TN_ABL != 1     // (ablation 1, timing only: no DMA after the prologue)
+      if (h + 3 < nh) issue(h + 3);
+#endif
+      const unsigned sb = (unsigned)(h % NSTAGE) * 32768u;
+      bf16x8 af[8], bfr[4];
+#if defined(CSN_TN_ABL) && CSN_TN_ABL == 2       // (ablation 2, timing only: no LDS reads)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bfr[j] = __builtin_bit_cast(bf16x8, (f32x4){(float)sb, 1.f, 2.f, (float)j});
+#pragma unroll
+      for (int i = 0; i < 8; ++i) af[i] = __builtin_bit_cast(bf16x8, (f32x4){(float)sb, 3.f, 2.f, (float)i});
+#else
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bfr[j] = tr_read_pair(b_addr[j] + sb + 16384u);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) af[i] = tr_read_pair(a_addr[i] + sb);
+#endif
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        // reads behind the ones MFMA group i needs: the pairs of A fragments i+1 .. 7
+        if (i == 0) asm volatile("s_waitcnt lgkmcnt(14)" ::: "memory");
+        else if (i == 1) asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory");
+        else if (i == 2) asm volatile("s_waitcnt lgkmcnt(10)" ::: "memory");
+        else if (i == 3) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+        else if (i == 4) asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+        else if (i == 5) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+        else if (i == 6) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+        if constexpr (COLSUM)
+          if (do_colsum && (i >> 1) == wn_s) acc_cs[i & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[i], acc_cs[i & 1], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      __builtin_amdgcn_s_barrier();
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();
+  } else {
 #pragma unroll
   for (int h = 0; h < NSTAGE - 1; ++h)
     if (h < nh) issue(h);
@@ -787,13 +856,21 @@ gemm_tn_256_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ Bm, 
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       }
       __builtin_amdgcn_sched_barrier(0);
+#ifdef CSN_TN_SETPRIO
+      __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
       for (int j = 0; j < 4; ++j)
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+#ifdef CSN_TN_SETPRIO
+      __builtin_amdgcn_s_setprio(0);
+#endif
       if constexpr (COLSUM)
         if (do_colsum && (i >> 1) == wn_s) acc_cs[i & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[i], acc_cs[i & 1], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
+  }
+
   }
 
   if (COLSUM && do_colsum && (lane >> 4) == 0) {       // D[n][m]: every row n holds the same sum; lanes 0..15 write column m
@@ -959,7 +1036,12 @@ int launch_gemm_tn_slabs(const void* A, const void* B, float* slabs, int64_t M, 
     const int nst = opt.tn_stages;
     const bf16_t* Ab = (const bf16_t*)A;
     const bf16_t* Bb = (const bf16_t*)B;
-    if (colsum) gemm_tn_256_kernel<4, true><<<grid, 512, 4 * 32768, st>>>(Ab, Bb, slabs, M, N, K, kper2, colsum);
+    if (!opt.tn_no_stagger && nst == 4) {      // (the default; CSN_TN_STAGES selects one of the single-phase rings)
+      if (int rc = ensure_dyn_lds<&gemm_tn_256_kernel<5, false, true>>(5 * 32768)) return rc;
+      if (int rc = ensure_dyn_lds<&gemm_tn_256_kernel<5, true, true>>(5 * 32768)) return rc;
+      if (colsum) gemm_tn_256_kernel<5, true, true><<<grid, 512, 5 * 32768, st>>>(Ab, Bb, slabs, M, N, K, kper2, colsum);
+      else gemm_tn_256_kernel<5, false, true><<<grid, 512, 5 * 32768, st>>>(Ab, Bb, slabs, M, N, K, kper2, nullptr);
+    } else if (colsum) gemm_tn_256_kernel<4, true><<<grid, 512, 4 * 32768, st>>>(Ab, Bb, slabs, M, N, K, kper2, colsum);
     else if (nst == 3) gemm_tn_256_kernel<3, false><<<grid, 512, 3 * 32768, st>>>(Ab, Bb, slabs, M, N, K, kper2, nullptr);
     else if (nst == 5) gemm_tn_256_kernel<5, false><<<grid, 512, 5 * 32768, st>>>(Ab, Bb, slabs, M, N, K, kper2, nullptr);
     else gemm_tn_256_kernel<4, false><<<grid, 512, 4 * 32768, st>>>(Ab, Bb, slabs, M, N, K, kper2, nullptr);

@@ -137,10 +137,15 @@ def test_gemm_tn(cuda, M, N, K, dt):
 
 
 @pytest.mark.parametrize("M,N,K,stages", [(512, 256, 8192, "5"), (3072, 768, 16000, "5"), (264, 520, 8256, "4"),
-                                            (768, 256, 12800, "3")])
+                                            (768, 256, 12800, "3"), (3072, 768, 32000, "4"), (512, 768, 8192 + 64, "4"),
+                                            (3072, 768, 16000, "4n")])
 def test_gemm_tn_256_tile_pipeline(cuda, M, N, K, stages):
-    """The 256 x 256 LDS-DMA weight-gradient kernel (ring of stages, counted waits) against float64 and, bit for
-    bit, against the register-staged 128 x 128 kernel run with the same K split."""
+    """The 256 x 256 LDS-DMA weight-gradient kernel against float64 and against the register-staged 128 x 128
+    kernel: "4" = the default, two wave groups one barrier interval apart on a ring of 5 stages; "3" / "5" / "4n"
+    (CSN_TN_NO_STAGGER) = the single-phase rings."""
+    if stages.endswith("n"):
+        stages = stages[:-1]
+        os.environ["CSN_TN_NO_STAGGER"] = "1"
     rng = np.random.default_rng(M + N + K)
     a = bf16_round(rng.standard_normal((K, M)).astype(np.float32))
     b = bf16_round(rng.standard_normal((K, N)).astype(np.float32))
@@ -151,6 +156,7 @@ def test_gemm_tn_256_tile_pipeline(cuda, M, N, K, stages):
         c2 = cabi.gemm_tn(dev_t(a, cuda, torch.bfloat16), dev_t(b, cuda, torch.bfloat16)).cpu().numpy()
     finally:
         del os.environ["CSN_TN_STAGES"]
+        os.environ.pop("CSN_TN_NO_STAGGER", None)
     np.testing.assert_allclose(c, want, atol=2e-4 * np.sqrt(K))
     np.testing.assert_array_equal(c, c2)
     os.environ["CSN_GEMM_NO_256"] = "1"
@@ -159,6 +165,30 @@ def test_gemm_tn_256_tile_pipeline(cuda, M, N, K, stages):
     finally:
         del os.environ["CSN_GEMM_NO_256"]
     np.testing.assert_allclose(c, c3, atol=1e-5 * np.sqrt(K))     # different K split: same products, other sum order
+
+
+def test_gemm_tn_staggered_ring_race_screen(cuda):
+    """The default weight-gradient kernel orders its LDS-DMA stages by counted waits and barriers only (two wave groups
+    one barrier interval apart, ring of 5): a misplaced wait shows up as RARE wrong tiles that come and go with the
+    memory load.  Screen: the same products, summed in the same order, as the single-phase ring -- bit for bit, 25
+    times per shape, with other work (a second stream hammering HBM) running beside it."""
+    rng = np.random.default_rng(11)
+    side = torch.cuda.Stream()
+    junk = torch.empty(64 << 20, dtype=torch.float32, device=cuda)
+    for (M, N, K) in ((3072, 768, 32768), (512, 256, 8192 + 192), (768, 768, 20480)):
+        a = dev_t(bf16_round(rng.standard_normal((K, M)).astype(np.float32)), cuda, torch.bfloat16)
+        b = dev_t(bf16_round(rng.standard_normal((K, N)).astype(np.float32)), cuda, torch.bfloat16)
+        os.environ["CSN_TN_NO_STAGGER"] = "1"
+        try:
+            want = cabi.gemm_tn(a, b)
+        finally:
+            del os.environ["CSN_TN_NO_STAGGER"]
+        for rep in range(25):
+            with torch.cuda.stream(side):
+                junk.add_(1.0)
+            got = cabi.gemm_tn(a, b)
+            assert torch.equal(got, want), (M, N, K, rep, float((got - want).abs().max()))
+        torch.cuda.synchronize()
 
 
 # ----------------------------------------------------------------------------------------------
