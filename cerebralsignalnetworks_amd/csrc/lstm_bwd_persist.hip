@@ -112,7 +112,6 @@ __global__ void __launch_bounds__(256) lstm_bwd_persist_kernel(PersistBwdArgs a)
   unsigned* const flags = S.flags + (size_t)mt * kPersistFlagLine;
   const size_t flag_step = (size_t)MT * kPersistFlagLine;
   const int t_hi = S.t_hi, nsteps = S.nsteps;
-  const bool full_tile = m0 + 64 <= B;
 
   // ---- is this group on one XCD?  (see lstm_fwd_persist.hip)
   bool local = false;
@@ -324,7 +323,6 @@ __global__ void __launch_bounds__(256) lstm_bwd_persist_kernel(PersistBwdArgs a)
         bstore_b128<true>(dst, o0, lo);
         bstore_b128<true>(dst, o1, hi);
       }
-      __builtin_amdgcn_sched_barrier(0);      // (pinned in front of the pass's other stores: the counted drain below relies on it)
       bf16x8* op = reinterpret_cast<bf16x8*>(dgates + ((size_t)t * B + row) * K + 4 * (size_t)uq);
       nt_store(op, lo);
       nt_store(op + 1, hi);
@@ -332,9 +330,7 @@ __global__ void __launch_bounds__(256) lstm_bwd_persist_kernel(PersistBwdArgs a)
       cc[ps] = cpv[ps];                       // c_{t-1} is the next step's c
     }
     CSN_BSTAMP(3);     // epilogue
-    // (counted: behind a wave's last hand-off store sit only the two row-major dgates stores of that pass, see the forward)
-    if (full_tile) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (full drain, not a counted one: see lstm_fwd_persist.hip)
     __syncthreads();
     CSN_BSTAMP(4);     // drain + barrier
     if (tid == 0) {

@@ -142,7 +142,6 @@ __global__ void __launch_bounds__(256) lstm_fwd_persist_kernel(PersistFwdArgs a)
   unsigned* const flags = S.flags + (size_t)mt * kPersistFlagLine;    // [T+1][MT][line]: word i = slice i has published
   const size_t flag_step = (size_t)MT * kPersistFlagLine;
   const int t_first = S.t0, nsteps = S.nsteps;
-  const bool full_tile = m0 + 64 <= B;
   // fused input projection: wave w contracts k-block w of the input features (I <= 128: at most one per wave)
   const bf16_t* const x_blk = S.x_blk;
   const bool fused = x_blk != nullptr;
@@ -371,7 +370,6 @@ __global__ void __launch_bounds__(256) lstm_fwd_persist_kernel(PersistFwdArgs a)
       bf16_t* hdst = h_blk_all + (size_t)(t + 1) * slab + blk_offset(row, uq, H);
       if (local) store_plain_b64(hdst, hn);
       else store_wt_b64(hdst, hn);
-      __builtin_amdgcn_sched_barrier(0);      // (pinned in front of the pass's other stores: the counted drain below relies on it)
       if (gates != nullptr) {
         bf16x8 lo = {(bf16_t)gi[0], (bf16_t)gf[0], (bf16_t)gg[0], (bf16_t)go[0], (bf16_t)gi[1], (bf16_t)gf[1], (bf16_t)gg[1], (bf16_t)go[1]};
         bf16x8 hi = {(bf16_t)gi[2], (bf16_t)gf[2], (bf16_t)gg[2], (bf16_t)go[2], (bf16_t)gi[3], (bf16_t)gf[3], (bf16_t)gg[3], (bf16_t)go[3]};
@@ -385,16 +383,13 @@ __global__ void __launch_bounds__(256) lstm_fwd_persist_kernel(PersistFwdArgs a)
                                   reinterpret_cast<bf16x4*>(h_all + ((size_t)(t + 1) * B + row) * H + uq));
     }
     CSN_PSTAMP(3);     // epilogue (LDS reads, math, store issue)
-    // publish: every storing wave waits for its hand-off stores, workgroup barrier (also frees `red`), one lane
-    // signals.  vmcnt counts in issue order: behind a wave's LAST hand-off store sit only the saved-tensor stores of
-    // that pass (gates x 2, c, h -- all issued when every row of the tile is a batch row), so a counted wait covers
-    // exactly the stores the readers need
-    if (full_tile) {
-      if (gates != nullptr) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
+    // publish: every storing wave drains, workgroup barrier (also frees `red`), one lane signals.
+    // (A COUNTED wait -- vmcnt(4): "all but the four saved-tensor stores behind the last hand-off store" -- was 1.7 %
+    // faster per launch and passed every test, until a semantically neutral reordering of the prologue made the
+    // H = 512 instantiation return stale rows with it and correct ones without it: whatever the cause -- store
+    // acknowledgements of different kinds overtaking each other, or compiler-placed spill traffic in the count --
+    // the hand-off may not depend on it.  Full drain.)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     CSN_PSTAMP(4);     // drain + barrier
     if (tid == 0) {

@@ -14,7 +14,7 @@
 //              registers of W_ih; layers above: the projection read from HBM.  On it: wait for the chain's counter,
 //              add the MFMA waves' tiles, gate math in the accumulator layout ((i, f, g, o) of one cell in one lane;
 //              c stays in registers), a wave-private LDS transpose, stores with consecutive lanes on consecutive
-//              bytes (the h hand-off block first), a COUNTED vmcnt wait that covers only that first store, the
+//              bytes (the h hand-off block first), a full store drain, the
 //              chain's flag.  Then it watches the flag line of the next step (scalar loads), and as soon as all 32
 //              slices have published, brings the chain's 16 x 768 slice of h_t into LDS (24 LDS-DMA pieces of 1 KB
 //              that already have the operand layout; the next input request goes out BEHIND them and a counted wait
@@ -199,7 +199,6 @@ __device__ __forceinline__ void ws_gate_wave(const PersistFwdArgs& a, const Pers
   unsigned* const flags = S.flags + ((size_t)mt * 4 + q) * kPersistFlagLine;
   const size_t flag_step = (size_t)MT * 4 * kPersistFlagLine;
   const int t_first = S.t0, nsteps = S.nsteps;
-  const bool full = r0 + 16 <= B;                      // every row of the chain is a real batch row
   char* const hbuf = smem + (size_t)q * kWsHBuf;                       // the chain's slice of h_{t-1}: 24 operand fragments
   char* const slots = smem + 4 * kWsHBuf + (size_t)q * kWsSlots;       // the MFMA waves' 8 tiles; then this wave's transpose area:
   char* const sg = slots;                                              // gates [16 rows][208 B]: 24 units x (i, f, g, o) bf16
@@ -365,14 +364,9 @@ __device__ __forceinline__ void ws_gate_wave(const PersistFwdArgs& a, const Pers
       }
     }
     CSN_WSTAMP(12);    // transpose reads + store issue
-    // only the hand-off store has to have landed before the flag: with every row real, the 3 (+3) stores behind it
-    // were all issued (non-empty lane sets), so a counted wait covers exactly that first one
-    if (full) {
-      if (gates != nullptr) ns_wait_vmcnt<6>();
-      else ns_wait_vmcnt<3>();
-    } else {
-      ns_wait_vmcnt<0>();
-    }
+    // every store of the step has landed before the flag (a counted wait that covered only the hand-off store was
+    // measured here first; counted waits on stores are not relied upon any more, see lstm_fwd_persist.hip)
+    ns_wait_vmcnt<0>();
     CSN_WSTAMP(13);    // hand-off store landed
     if (lane == 0) {
       unsigned* fl = flags + (size_t)(t + 1) * flag_step + slice;
