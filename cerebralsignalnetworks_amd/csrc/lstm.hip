@@ -77,7 +77,7 @@ static WsLayout make_layout(const csnLstmDesc& d, int training, const Options& o
       L.whht_blk = take(G * H * 2);
       L.hblk[0] = take(Bpad * H * 2);
       L.hblk[1] = take(Bpad * H * 2);
-      if (w.persist) L.h_blk_all = take(((size_t)d.T + 1) * Bpad * H * 2);
+      if (w.persist) L.h_blk_all = take(((size_t)(d.T < 3 ? 3 : d.T) + 1) * Bpad * H * 2);   // (>= 4: the data-poll hand-off uses the first 4 as a ring)
     } else {
       L.whh = take(G * H * es);
       L.whht = take(G * H * es);
@@ -94,7 +94,7 @@ static WsLayout make_layout(const csnLstmDesc& d, int training, const Options& o
         L.dgblk[0] = take(Bpad * G * 2);
         L.dgblk[1] = take(Bpad * G * 2);
       }
-      if (w.persist_bwd) L.dg_blk_all = take((size_t)d.T * Bpad * G * 2);
+      if (w.persist_bwd) L.dg_blk_all = take((size_t)(d.T < 4 ? 4 : d.T) * Bpad * G * 2);   // (>= 4: ring of the data-poll hand-off)
     }
     size_t a = gemm_tn_scratch_bytes(G, I, TB, opt), b = gemm_tn_scratch_bytes(G, H, TB, opt);
     if (a > tn_bytes) tn_bytes = a;
@@ -668,6 +668,10 @@ static int forward_persist(Plan& P, char* ws, int training, hipStream_t st, Side
   a.error_flag = (unsigned*)(ws + w.status);
   a.B = B; a.H = H; a.T = T; a.Bpad = Bpad; a.MT = MT;
   a.rotate = !P.opt.no_rotate;
+  a.data_polls = (!w.fwd_ns && !P.opt.fwd_flags) ? (P.opt.dpoll_no_hint ? 2 : 1) : 0;
+  if (a.data_polls)        // the ring of 4 hand-off slabs of every layer starts as sentinel (lstm_fwd_persist.hip)
+    for (int l = 0; l < NL; ++l)
+      CSN_HIP_CHECK(hipMemsetAsync(ws + w.layer[l].h_blk_all, 0xff, (size_t)4 * Bpad * H * 2, st));
   a.chains = (w.fwd_ns && H == 768 && P.opt.fwd_ws) ? 4 : 1;
   a.half_tiles = (w.fwd_ns && H == 768 && P.opt.fwd_halves && a.chains == 1) ? 1 : 0;
   int n_launch = 0;
@@ -992,6 +996,10 @@ static int backward_persist(Plan& P, char* ws, const float* dy_last,
   a.xcd_groups = 1;
   a.grid_slices = 32;
   a.rotate = !P.opt.no_rotate;
+  a.data_polls = P.opt.bwd_flags ? 0 : (P.opt.dpoll_no_hint ? 2 : 1);
+  if (a.data_polls)        // the ring of 4 hand-off slabs of every layer starts as sentinel (lstm_bwd_persist.hip)
+    for (int l = 0; l < NL; ++l)
+      CSN_HIP_CHECK(hipMemsetAsync(ws + w.layer[l].dg_blk_all, 0xff, (size_t)4 * Bpad * G * 2, st));
   int n_launch = 0;
   BesideGemm pending[3];           // GEMMs of the chunks finished by the previous launch
   int npending = 0;

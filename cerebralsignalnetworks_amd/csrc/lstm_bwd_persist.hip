@@ -25,7 +25,7 @@
 #ifndef CSN_STAMP_BLOCK
 #define CSN_STAMP_BLOCK 11     // group 3 (layer 0 at cfg2), slice 1; 15 = group 7 (layer 1)
 #endif
-__device__ unsigned long long g_bstamps[8];
+__device__ unsigned long long g_bstamps[16];
 #define CSN_BSTAMP(i)                                                          \
   do {                                                                         \
     __builtin_amdgcn_sched_barrier(0);                                         \
@@ -42,24 +42,26 @@ __device__ unsigned long long g_bstamps[8];
 
 namespace csn {
 
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+
 static constexpr unsigned long long kBwdSpinTimeoutTicks = 20000000ull;   // 0.2 s of the 100 MHz wall clock
 
 typedef __attribute__((ext_vector_type(4))) unsigned bu32x4;
 
-__device__ __forceinline__ bf16x8 bload_sc1_b128(__amdgpu_buffer_rsrc_t rsrc, unsigned byte_off) {
-  bu32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)byte_off, 0, 16);   // aux 16 = sc1: L1 bypassed
+__device__ __forceinline__ bf16x8 bload_sc1_b128(__amdgpu_buffer_rsrc_t rsrc, unsigned byte_off, int soff = 0) {
+  bu32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)byte_off, soff, 16);   // aux 16 = sc1: L1 bypassed
   union { bu32x4 u; bf16x8 b; } cvt;
   cvt.u = v;
   return cvt.b;
 }
 template <bool WT>
-__device__ __forceinline__ void bstore_b128(__amdgpu_buffer_rsrc_t rsrc, unsigned byte_off, const bf16x8& v) {
+__device__ __forceinline__ void bstore_b128(__amdgpu_buffer_rsrc_t rsrc, unsigned byte_off, const bf16x8& v, int soff = 0) {
   union { bu32x4 u; bf16x8 b; } cvt;
   cvt.b = v;
-  __builtin_amdgcn_raw_buffer_store_b128(cvt.u, rsrc, (int)byte_off, 0, WT ? 16 : 0);   // sc1 = write-through
+  __builtin_amdgcn_raw_buffer_store_b128(cvt.u, rsrc, (int)byte_off, soff, WT ? 16 : 0);   // sc1 = write-through
 }
 
-template <int NUT, int KS>
+template <int NUT, int KS, bool DPOLL>
 __global__ void __launch_bounds__(256) lstm_bwd_persist_kernel(PersistBwdArgs a) {
   constexpr int RING = KS >= 32 ? 3 : (KS < 5 ? KS : 5);   // k-blocks of dgates in flight per wave (3 at H = 1024: register budget)
   constexpr int NT = 4 * NUT;                    // accumulator tiles per wave (4 row groups x NUT unit tiles)
@@ -112,6 +114,9 @@ __global__ void __launch_bounds__(256) lstm_bwd_persist_kernel(PersistBwdArgs a)
   unsigned* const flags = S.flags + (size_t)mt * kPersistFlagLine;
   const size_t flag_step = (size_t)MT * kPersistFlagLine;
   const int t_hi = S.t_hi, nsteps = S.nsteps;
+  // hand-off by DATA (see lstm_fwd_persist.hip): ring of 4 slabs, dgates_s in slot s & 3, unwritten regions hold the
+  // all-ones sentinel; no store drain and no flag on the producer side
+  constexpr bool dpoll = DPOLL;
 
   // ---- is this group on one XCD?  (see lstm_fwd_persist.hip)
   bool local = false;
@@ -194,6 +199,11 @@ __global__ void __launch_bounds__(256) lstm_bwd_persist_kernel(PersistBwdArgs a)
     }
   };
   request_saved(t_hi);
+  // data polls: ONE buffer resource over the ring of 4 slabs, the slab of a step is a scalar offset -- a resource per
+  // slab and use (read, write, re-arm) ran the kernel out of SGPRs; flags: a resource per slab (T slabs can exceed 2 GiB)
+  const __amdgpu_buffer_rsrc_t ring_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)dg_blk_all, 0, (int)((size_t)4 * slab * 2), 0x00020000);
+  const int slab_bytes = (int)(slab * 2);
 #ifdef CSN_PSTAMPS
   unsigned long long last_ = wall_clock64();
   if (tid == 0 && blockIdx.x == CSN_STAMP_BLOCK) atomicAdd(&g_bstamps[6], last_ - t_entry_);   // prologue of this launch
@@ -223,9 +233,22 @@ __global__ void __launch_bounds__(256) lstm_bwd_persist_kernel(PersistBwdArgs a)
       // loads -- the polling wave is the loading wave, no workgroup barrier.
       {
         const int npw = nslices >> 2;
-        const unsigned* fl = flags + (size_t)(t + 1) * flag_step + wave * npw + (lane < npw ? lane : 0);
+        // flags: word i of the (t+1, M-tile) line.  Data polls: four words per producer, one from the LAST store
+        // instruction of each of its waves (thread 64 w + 63, last pass, second piece) -- a hint that the whole
+        // region is there (watching the first word stored made the consumers start early and redo the phase)
+        const unsigned* fl;
+        if constexpr (dpoll) {
+          const int pi = lane < 4 * npw ? lane >> 2 : 0, pw = lane & 3;
+          const int pp = 64 * pw + 63 + (NPASS - 1) * 256;                 // (NPAIR is a multiple of 256: every thread has a pair in the last pass)
+          const int64_t prow_w = m0 + pp / QPR, pcol_w = 4 * (int64_t)((wave * npw + pi) * 16 * NUT + 4 * (pp % QPR)) + 8;
+          fl = reinterpret_cast<const unsigned*>(dg_blk_all + (size_t)((t + 1) & 3) * slab + blk_offset(prow_w, pcol_w, K));
+        } else {
+          fl = flags + (size_t)(t + 1) * flag_step + wave * npw + (lane < npw ? lane : 0);
+        }
+        const unsigned not_yet = dpoll ? 0xffffffffu : 0u;
         const unsigned long long t_begin = wall_clock64();
-        while (!__all(__hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+        // (data_polls == 2, a test switch: no hint, load straight away -- every step then goes through the re-read path)
+        while (!(dpoll && a.data_polls == 2) && !__all(__hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != not_yet)) {
           __builtin_amdgcn_s_sleep(1);
           if (__hip_atomic_load(a.error_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
           if (wall_clock64() - t_begin > kBwdSpinTimeoutTicks) {
@@ -234,35 +257,87 @@ __global__ void __launch_bounds__(256) lstm_bwd_persist_kernel(PersistBwdArgs a)
           }
         }
       }
+#ifdef CSN_BWD_SETTLE
+      if constexpr (dpoll) __builtin_amdgcn_s_sleep(CSN_BWD_SETTLE);      // (experiment: let the producers' other pieces land)
+#endif
       CSN_BSTAMP(0);   // wait for dgates_{t+1}
-      const __amdgpu_buffer_rsrc_t src = __builtin_amdgcn_make_buffer_rsrc(
-          (void*)(dg_blk_all + (size_t)(t + 1) * slab), 0, (int)(slab * 2), 0x00020000);
+      const __amdgpu_buffer_rsrc_t slabs_rsrc = dpoll ? ring_rsrc : __builtin_amdgcn_make_buffer_rsrc(
+          (void*)(dg_blk_all + (size_t)(t + 1) * slab), 0, slab_bytes, 0x00020000);
+      const int src_off = dpoll ? __builtin_amdgcn_readfirstlane(((t + 1) & 3) * slab_bytes) : 0;
+      // (the k-block walk offset re-enters the step as an opaque scalar: left visible as a loop invariant, the compiler
+      // keeps the 24 rotated block offsets of every load in SGPRs across the steps and runs out of them)
+      int rot_t = rot;
+#if !defined(CSN_BWD_ABL) || CSN_BWD_ABL != 3
+      if constexpr (dpoll) asm volatile("" : "+s"(rot_t));
+#endif
       const unsigned base = (unsigned)((((size_t)(m0 >> 4) * kblocks + ks_beg) * 512 + lane * 8) * 2);
       // ring of RING k-blocks: issue order = consumption order (pinned), so the MFMAs of a k-block wait only
-      // for its own 4 loads while the next RING-1 k-blocks are in flight
-      bf16x8 df[RING][4];
-#pragma unroll
-      for (int kb = 0; kb < RING; ++kb) {
-#pragma unroll
-        for (int rg = 0; rg < 4; ++rg)
-          df[kb][rg] = bload_sc1_b128(src, base + (unsigned)(rg * kblocks + (kb + rot) % KS) * 1024u);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-#pragma unroll
-      for (int kb = 0; kb < KS; ++kb) {
-#pragma unroll
-        for (int rg = 0; rg < 4; ++rg)
-#pragma unroll
-          for (int ut = 0; ut < NUT; ++ut)   // D[row = unit][col = batch row]
-            acc[rg][ut] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[kb][ut], df[kb % RING][rg], acc[rg][ut], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (kb + RING < KS) {
+      // for its own 4 loads while the next RING-1 k-blocks are in flight.
+      // Data polls: every piece that was multiplied must have been data, not the sentinel -- checked ONCE behind the
+      // MFMAs (a test + branch per k-block cost 1 us per step here, a running minimum over the loaded words 0.8): if
+      // the watched words were ahead of their neighbours, the whole phase is redone.
+      const unsigned long long t_phase = wall_clock64();
+      bool again = false;
+      do {
+        if (again) {
+          __builtin_amdgcn_s_sleep(1);
 #pragma unroll
           for (int rg = 0; rg < 4; ++rg)
-            df[kb % RING][rg] = bload_sc1_b128(src, base + (unsigned)(rg * kblocks + (kb + RING + rot) % KS) * 1024u);
+#pragma unroll
+            for (int ut = 0; ut < NUT; ++ut) acc[rg][ut] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        bf16x8 df[RING][4];
+        // (the rotated k-block walk as ONE running scalar offset: k-block (i + rot) % KS of the i-th group issued)
+        int kbo = rot_t * 1024;
+        auto issue_group = [&](int slot) {
+#pragma unroll
+          for (int rg = 0; rg < 4; ++rg)
+            df[slot][rg] = bload_sc1_b128(slabs_rsrc, base + (unsigned)(rg * kblocks) * 1024u, src_off + kbo);
+          kbo = kbo + 1024 == KS * 1024 ? 0 : kbo + 1024;
+        };
+#pragma unroll
+        for (int kb = 0; kb < RING; ++kb) {
+          issue_group(kb);
           __builtin_amdgcn_sched_barrier(0);
         }
-      }
+#pragma unroll
+        for (int kb = 0; kb < KS; ++kb) {
+#pragma unroll
+          for (int rg = 0; rg < 4; ++rg)
+#pragma unroll
+            for (int ut = 0; ut < NUT; ++ut)   // D[row = unit][col = batch row]
+              acc[rg][ut] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[kb][ut], df[kb % RING][rg], acc[rg][ut], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          if (kb + RING < KS) {
+            issue_group(kb % RING);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+        again = false;
+        if constexpr (dpoll) {
+          // the sentinel is a pair of bf16 NaNs: a piece that was still the sentinel when it was multiplied has
+          // poisoned every accumulator element of its batch row -- one sum over the 32 accumulator registers finds it
+          float chk = 0.f;
+#pragma unroll
+          for (int rg = 0; rg < 4; ++rg)
+#pragma unroll
+            for (int ut = 0; ut < NUT; ++ut) chk += (acc[rg][ut][0] + acc[rg][ut][1]) + (acc[rg][ut][2] + acc[rg][ut][3]);
+#if defined(CSN_BWD_ABL) && CSN_BWD_ABL == 2
+          if (false) {
+#else
+          if (__builtin_expect(!__all(chk == chk), 0)) {
+#endif
+#ifdef CSN_PSTAMPS
+            if (lane == 0) atomicAdd(&g_bstamps[8 + wave], 1ull);        // (diagnostic: phases redone, per wave, all workgroups)
+#endif
+            again = __hip_atomic_load(a.error_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u;
+            if (wall_clock64() - t_phase > kBwdSpinTimeoutTicks) {
+              __hip_atomic_store(a.error_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              again = false;
+            }
+          }
+        }
+      } while (again);
     }
     // the next step's saved tensors: in flight during this step's reduction and epilogue
     if (s + 1 < nsteps) request_saved(t - 1);
@@ -278,11 +353,49 @@ __global__ void __launch_bounds__(256) lstm_bwd_persist_kernel(PersistBwdArgs a)
     __syncthreads();
     CSN_BSTAMP(2);     // LDS write + barrier
 
-    const __amdgpu_buffer_rsrc_t dst = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(dg_blk_all + (size_t)t * slab), 0, (int)(slab * 2), 0x00020000);
+    // data polls: re-arm slot (t - 2) & 3 (it holds dgates_{t+2}: every producer has published dgates_{t+1}, so all of
+    // them have read it; it is looked at again at step t-3, after this workgroup's dgates_{t-1} was consumed, which
+    // is stored behind loads that retire these stores -- the argument of lstm_fwd_persist.hip, mirrored in time)
+#if !defined(CSN_BWD_ABL) || CSN_BWD_ABL != 1
+    if (dpoll) {
+      const int arm_off = __builtin_amdgcn_readfirstlane(((t + 2) & 3) * slab_bytes);
+      const bf16x8 sent = __builtin_bit_cast(bf16x8, (u32x4){0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu});
+#pragma unroll
+      for (int ps = 0; ps < NPASS; ++ps) {
+        const unsigned o0 = (unsigned)(blk_offset(prow[ps], 4 * (int64_t)puq[ps], K) * 2);
+        const unsigned o1 = (unsigned)(blk_offset(prow[ps], 4 * (int64_t)puq[ps] + 8, K) * 2);
+        if (local) {
+          bstore_b128<false>(ring_rsrc, o0, sent, arm_off);
+          bstore_b128<false>(ring_rsrc, o1, sent, arm_off);
+        } else {
+          bstore_b128<true>(ring_rsrc, o0, sent, arm_off);
+          bstore_b128<true>(ring_rsrc, o1, sent, arm_off);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#endif
+
+    const __amdgpu_buffer_rsrc_t slabs_rsrc = dpoll ? ring_rsrc : __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(dg_blk_all + (size_t)t * slab), 0, slab_bytes, 0x00020000);
+    const int dst_off = dpoll ? __builtin_amdgcn_readfirstlane((t & 3) * slab_bytes) : 0;
 #pragma unroll
     for (int ps = 0; ps < NPASS; ++ps) {
-      if (!pok[ps]) continue;
+      if (!pok[ps]) {
+        if (dpoll) {        // padding rows of the last M-tile: zeros instead of the sentinel (they feed only their own outputs)
+          const bf16x8 z = __builtin_bit_cast(bf16x8, (u32x4){0u, 0u, 0u, 0u});
+          const unsigned z0 = (unsigned)(blk_offset(prow[ps], 4 * (int64_t)puq[ps], K) * 2);
+          const unsigned z1 = (unsigned)(blk_offset(prow[ps], 4 * (int64_t)puq[ps] + 8, K) * 2);
+          if (local) {
+            bstore_b128<false>(slabs_rsrc, z0, z, dst_off);
+            bstore_b128<false>(slabs_rsrc, z1, z, dst_off);
+          } else {
+            bstore_b128<true>(slabs_rsrc, z0, z, dst_off);
+            bstore_b128<true>(slabs_rsrc, z1, z, dst_off);
+          }
+        }
+        continue;
+      }
       const int rl = prl[ps], jq = pjq[ps], row = prow[ps], uq = puq[ps];
       const int idx = ((rl >> 4) * NUT + (jq >> 2)) * 65 + (rl & 15) + 16 * (jq & 3);
       float4 sm = red[idx];
@@ -317,11 +430,11 @@ __global__ void __launch_bounds__(256) lstm_bwd_persist_kernel(PersistBwdArgs a)
       const unsigned o0 = (unsigned)(blk_offset(row, 4 * (int64_t)uq, K) * 2);
       const unsigned o1 = (unsigned)(blk_offset(row, 4 * (int64_t)uq + 8, K) * 2);
       if (local) {
-        bstore_b128<false>(dst, o0, lo);
-        bstore_b128<false>(dst, o1, hi);
+        bstore_b128<false>(slabs_rsrc, o0, lo, dst_off);
+        bstore_b128<false>(slabs_rsrc, o1, hi, dst_off);
       } else {
-        bstore_b128<true>(dst, o0, lo);
-        bstore_b128<true>(dst, o1, hi);
+        bstore_b128<true>(slabs_rsrc, o0, lo, dst_off);
+        bstore_b128<true>(slabs_rsrc, o1, hi, dst_off);
       }
       bf16x8* op = reinterpret_cast<bf16x8*>(dgates + ((size_t)t * B + row) * K + 4 * (size_t)uq);
       nt_store(op, lo);
@@ -330,10 +443,10 @@ __global__ void __launch_bounds__(256) lstm_bwd_persist_kernel(PersistBwdArgs a)
       cc[ps] = cpv[ps];                       // c_{t-1} is the next step's c
     }
     CSN_BSTAMP(3);     // epilogue
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (full drain, not a counted one: see lstm_fwd_persist.hip)
+    if (!dpoll) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (full drain, not a counted one: see lstm_fwd_persist.hip)
     __syncthreads();
     CSN_BSTAMP(4);     // drain + barrier
-    if (tid == 0) {
+    if (!dpoll && tid == 0) {
       unsigned* fl = flags + (size_t)t * flag_step + slice;
       if (local) *fl = 1u;
       else __hip_atomic_store(fl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -355,7 +468,8 @@ int bwd_persist_slices(int H) { return H / 32; }
 template <int NUT, int KS>
 static int launch_bwd_persist_t(const PersistBwdArgs& a, hipStream_t st) {
   size_t lds = (size_t)4 * 4 * NUT * 65 * sizeof(float4);
-  if (int rc = ensure_dyn_lds<&lstm_bwd_persist_kernel<NUT, KS>>((int)kBesideLdsBytes + 64)) return rc;
+  if (int rc = ensure_dyn_lds<&lstm_bwd_persist_kernel<NUT, KS, false>>((int)kBesideLdsBytes + 64)) return rc;
+  if (int rc = ensure_dyn_lds<&lstm_bwd_persist_kernel<NUT, KS, true>>((int)kBesideLdsBytes + 64)) return rc;
   const unsigned nslices = (unsigned)(a.H / (16 * NUT));
   PersistBwdArgs b = a;
   if (b.xcd_groups) {
@@ -367,7 +481,8 @@ static int launch_bwd_persist_t(const PersistBwdArgs& a, hipStream_t st) {
     }
   }
   const unsigned grid = b.xcd_groups ? 8u * (unsigned)b.grid_slices : nslices * (unsigned)(b.MT * b.nslots);
-  lstm_bwd_persist_kernel<NUT, KS><<<dim3(grid), 256, lds, st>>>(b);
+  if (b.data_polls) lstm_bwd_persist_kernel<NUT, KS, true><<<dim3(grid), 256, lds, st>>>(b);
+  else lstm_bwd_persist_kernel<NUT, KS, false><<<dim3(grid), 256, lds, st>>>(b);
   CSN_LAUNCH_CHECK();
   return CSN_OK;
 }
@@ -395,7 +510,7 @@ int launch_bwd_persist(const PersistBwdArgs& a, hipStream_t st) {
 
 #ifdef CSN_PSTAMPS
 extern "C" int csn_debug_read_bstamps(unsigned long long* out) {
-  unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long z[16] = {0};
   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bstamps), sizeof(z)) != hipSuccess) return 1;
   if (hipMemcpyToSymbol(HIP_SYMBOL(g_bstamps), z, sizeof(z)) != hipSuccess) return 1;
   return 0;

@@ -76,6 +76,7 @@ struct PersistFwdArgs {
   int ngemm;
   int grid_slices;
   int half_tiles;          // K2 x N2 body pipelined over 32-row halves: the flag lines are [T+1][MT][2][line]
+  int data_polls;          // K-split kernel: hand-off by sentinel data in a ring of 4 slabs (no flags, no store drain); the host fills the 4 slabs with 0xff per forward
   int chains;              // 4: the wave-specialised body (lstm_fwd_ws.hip), four 16-row chains per tile: flag lines [T+1][MT][4][line]
   // xcd_groups != 0: 1-D grid of 8 * nslices workgroups; the workgroups that share (blockIdx.x % 8) form one
   // hand-off group (a slot's M-tile) -- under the round-robin dispatch they share an XCD, which each group
@@ -119,6 +120,7 @@ struct PersistBwdArgs {
   int grid_slices;         // xcd_groups: the grid is 8 * grid_slices workgroups (>= slices per group)
   int xcd_groups;
   int rotate;              // != 0: each workgroup walks the k-blocks from its own offset (changes the summation order)
+  int data_polls;          // hand-off by sentinel data in a ring of 4 slabs (the host fills them with 0xff per backward)
   unsigned long long* agree;
   unsigned* error_flag;
   int B, H, T, Bpad, MT;

@@ -67,9 +67,9 @@ static constexpr unsigned long long kSpinTimeoutTicks = 20000000ull;   // 0.2 s 
 
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
-__device__ __forceinline__ bf16x8 load_sc1_b128(__amdgpu_buffer_rsrc_t rsrc, int byte_off) {
+__device__ __forceinline__ bf16x8 load_sc1_b128(__amdgpu_buffer_rsrc_t rsrc, int byte_off, int soff = 0) {
   // aux = 16: sc1 (agent-coherent, bypasses this CU's L1; MI355X_MICROARCH.md visibility table)
-  u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_off, 0, 16);
+  u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_off, soff, 16);
   union { u32x4 u; bf16x8 b; } cvt;
   cvt.u = v;
   return cvt.b;
@@ -105,7 +105,7 @@ __device__ __forceinline__ T bounded_poll(const T* p, unsigned* error_flag, Pred
 #ifndef CSN_FWD_RING
 #define CSN_FWD_RING 4
 #endif
-template <int NQ, int KS>
+template <int NQ, int KS, bool DPOLL>
 __global__ void __launch_bounds__(256) lstm_fwd_persist_kernel(PersistFwdArgs a) {
   constexpr int NT = 4 * NQ;
   constexpr int NPAIR = 64 * NQ;
@@ -142,6 +142,10 @@ __global__ void __launch_bounds__(256) lstm_fwd_persist_kernel(PersistFwdArgs a)
   unsigned* const flags = S.flags + (size_t)mt * kPersistFlagLine;    // [T+1][MT][line]: word i = slice i has published
   const size_t flag_step = (size_t)MT * kPersistFlagLine;
   const int t_first = S.t0, nsteps = S.nsteps;
+  // Hand-off by DATA (a.data_polls): the slabs form a ring of 4 whose unwritten regions hold a sentinel (all ones: two
+  // bf16 NaNs, which h = o tanh(c) never is); a consumer watches one word per producer and then verifies every
+  // 8-byte piece it loaded, so the producers neither drain their stores nor set a flag.  See the step loop.
+  constexpr bool dpoll = DPOLL;      // (compile time: as a run-time switch its branches slowed the flag form down by 4 %)
   // fused input projection: wave w contracts k-block w of the input features (I <= 128: at most one per wave)
   const bf16_t* const x_blk = S.x_blk;
   const bool fused = x_blk != nullptr;
@@ -260,6 +264,10 @@ __global__ void __launch_bounds__(256) lstm_fwd_persist_kernel(PersistFwdArgs a)
       for (int i = 0; i < 8; ++i) cur[i] = nxt[i];
     }
 
+    // slab (ring slot) this step reads h_{t-1} from / writes h_t to
+    const size_t slot_in = dpoll ? (size_t)(t & 3) : (size_t)t;
+    const size_t slot_out = dpoll ? (size_t)((t + 1) & 3) : (size_t)(t + 1);
+
     f32x4 acc[4][NQ];
 #pragma unroll
     for (int rg = 0; rg < 4; ++rg)
@@ -281,9 +289,25 @@ __global__ void __launch_bounds__(256) lstm_fwd_persist_kernel(PersistFwdArgs a)
       // no workgroup barrier, the polling wave is the loading wave.
       {
         const int npw = nslices >> 2;
-        const unsigned* fl = flags + (size_t)t * flag_step + wave * npw + (lane < npw ? lane : 0);
+        // flags: word i of the (t, M-tile) line.  Data polls: four words per producer, one from the LAST store
+        // instruction of each of its waves (thread 64 w + 63 in the last pass in which it owns a pair) -- a hint
+        // that the whole region is there; the proof is the check of every piece below
+        const unsigned* fl;
+        if constexpr (dpoll) {
+          const int pi = lane < 4 * npw ? lane >> 2 : 0, pw = lane & 3;
+          int pp = 64 * pw + 63;
+#pragma unroll
+          for (int ps = 1; ps < NPASS; ++ps)
+            if (64 * pw + 63 + ps * 256 < NPAIR) pp = 64 * pw + 63 + ps * 256;
+          fl = reinterpret_cast<const unsigned*>(h_blk_all + slot_in * slab +
+                                                 blk_offset(m0 + pp / NQ, (wave * npw + pi) * 4 * NQ + 4 * (pp % NQ), H));
+        } else {
+          fl = flags + (size_t)t * flag_step + wave * npw + (lane < npw ? lane : 0);
+        }
+        const unsigned not_yet = dpoll ? 0xffffffffu : 0u;
         const unsigned long long t_begin = wall_clock64();
-        while (!__all(__hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+        // (data_polls == 2, a test switch: no hint, load straight away -- every step then goes through the re-read path)
+        while (!(dpoll && a.data_polls == 2) && !__all(__hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != not_yet)) {
           __builtin_amdgcn_s_sleep(1);
           if (__hip_atomic_load(a.error_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
           if (wall_clock64() - t_begin > kSpinTimeoutTicks) {
@@ -293,19 +317,53 @@ __global__ void __launch_bounds__(256) lstm_fwd_persist_kernel(PersistFwdArgs a)
         }
       }
       CSN_PSTAMP(0);   // wait for h_{t-1}
-      const int base = (int)(((size_t)t * slab + ((size_t)(m0 >> 4) * kblocks + ks_beg) * 512 + lane * 8) * 2);
+      const int base = (int)((slot_in * slab + ((size_t)(m0 >> 4) * kblocks + ks_beg) * 512 + lane * 8) * 2);
       // issue order = consumption order (k-step major), pinned, so the MFMAs of k-step ks wait only for its
       // own 4 loads (counted vmcnt) while the younger ones are still in flight
       constexpr int RING = KS > CSN_FWD_RING ? CSN_FWD_RING : KS;      // k-blocks of h in flight per wave (registers)
       bf16x8 hf[RING][4];
+      // (the rotated k-block walk as ONE running scalar offset: k-block (i + rot) % KS of the i-th group issued; as
+      // per-load constants the compiler kept them in SGPRs across the steps)
+      int rot_t = rot;
+      asm volatile("" : "+s"(rot_t));
+      int kbo = rot_t * 1024;
+      auto issue_group = [&](int slot) {
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) hf[slot][rg] = load_sc1_b128(hsrc, base + rg * kblocks * 1024, kbo);
+        kbo = kbo + 1024 == KS * 1024 ? 0 : kbo + 1024;
+      };
 #pragma unroll
       for (int ks = 0; ks < RING; ++ks) {
-#pragma unroll
-        for (int rg = 0; rg < 4; ++rg) hf[ks][rg] = load_sc1_b128(hsrc, base + (rg * kblocks + (ks + rot) % KS) * 1024);
+        issue_group(ks);
         __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
+        if (dpoll) {
+          // every 8-byte piece (one producer store) of the four fragments is data, not the sentinel; otherwise the
+          // watched word was ahead of its neighbours: re-read this k-block until it is whole
+          auto whole = [&]() {
+            bool ok = true;
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+              const u32x4 u = __builtin_bit_cast(u32x4, hf[ks % RING][rg]);
+              ok = ok && u[0] != 0xffffffffu && u[2] != 0xffffffffu;
+            }
+            return __all(ok);
+          };
+          if (__builtin_expect(!whole(), 0)) {
+            const unsigned long long t_begin = wall_clock64();
+            do {
+              __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+              for (int rg = 0; rg < 4; ++rg) hf[ks % RING][rg] = load_sc1_b128(hsrc, base + (rg * kblocks + (ks + rot) % KS) * 1024);
+              if (wall_clock64() - t_begin > kSpinTimeoutTicks) {
+                __hip_atomic_store(a.error_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+              }
+            } while (!whole() && __hip_atomic_load(a.error_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u);
+          }
+        }
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg)
 #pragma unroll
@@ -313,9 +371,7 @@ __global__ void __launch_bounds__(256) lstm_fwd_persist_kernel(PersistFwdArgs a)
             acc[rg][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[ks][j], hf[ks % RING][rg], acc[rg][j], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
         if (ks + RING < KS) {
-#pragma unroll
-          for (int rg = 0; rg < 4; ++rg)
-            hf[ks % RING][rg] = load_sc1_b128(hsrc, base + (rg * kblocks + (ks + RING + rot) % KS) * 1024);
+          issue_group(ks % RING);
           __builtin_amdgcn_sched_barrier(0);
         }
       }
@@ -342,9 +398,43 @@ __global__ void __launch_bounds__(256) lstm_fwd_persist_kernel(PersistFwdArgs a)
     __syncthreads();
     CSN_PSTAMP(2);     // LDS write + barrier
 
+    // Data polls: re-arm a ring slot with the sentinel.  Ring of 4: h_s lives in slot (s + 1) & 3; slot (t + 3) & 3 holds
+    // h_{t-2} and will hold h_{t+2}.
+    //   safe to overwrite: past the barrier above all four waves have seen the watched word of h_{t-1} from every
+    //     producer of the group, and a producer writes h_{t-1} only after it has read h_{t-2}.  (NOT at the top of the
+    //     step: a workgroup that has not waited for h_{t-1} yet knows nothing about slower neighbours still reading
+    //     h_{t-2} -- found as a time-out of the one-launch-per-layer form, where the skew is larger.)
+    //   visible in time: a consumer looks at this slot at step t+3, after it has consumed this workgroup's h_{t+1};
+    //     h_{t+1} is stored behind the loads of step t+1, whose return (vmcnt retires in order) means these stores
+    //     were acknowledged -- so the sentinel is in L2 before h_{t+1} is even issued, with no wait spent on it.
+    //     (A ring of 3 -- re-arming the slot of h_{t+1} -- would leave only issue order between the sentinel and the
+    //     h_t the consumer has to see first.)
+    //   never over data: h_{t+2} is stored two steps from now, by this same wave.
+    if (dpoll) {
+#pragma unroll
+      for (int ps = 0; ps < NPASS; ++ps) {
+        if (tid + ps * 256 >= NPAIR) continue;      // (rows beyond B are padding rows of the slab: re-armed like the rest)
+        unsigned long long* sp = reinterpret_cast<unsigned long long*>(
+            h_blk_all + (size_t)((t + 3) & 3) * slab + blk_offset(prow[ps], puq[ps], H));
+        if (local) *sp = ~0ull;
+        else __hip_atomic_store(sp, ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+
+
 #pragma unroll
     for (int ps = 0; ps < NPASS; ++ps) {
-      if (!pok[ps]) continue;
+      if (!pok[ps]) {
+        // padding rows of the last M-tile: nobody computes them, but with data polls their pieces must stop being
+        // the sentinel (zeros: the rows feed only their own, never stored, outputs)
+        if (dpoll && tid + ps * 256 < NPAIR) {
+          unsigned long long* zp = reinterpret_cast<unsigned long long*>(h_blk_all + slot_out * slab + blk_offset(prow[ps], puq[ps], H));
+          if (local) *zp = 0ull;
+          else __hip_atomic_store(zp, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        continue;
+      }
       const int rl = prl[ps], j = pj[ps], row = prow[ps], uq = puq[ps];
       float gi[4], gf[4], gg[4], go[4], cn[4], hn[4];
       const float cpv[4] = {cst[ps].x, cst[ps].y, cst[ps].z, cst[ps].w};
@@ -367,7 +457,7 @@ __global__ void __launch_bounds__(256) lstm_fwd_persist_kernel(PersistFwdArgs a)
       }
       cst[ps] = make_float4(cn[0], cn[1], cn[2], cn[3]);
       // the hand-off payload first: plain stores stay in this XCD's L2 (L2-local groups), write-through otherwise
-      bf16_t* hdst = h_blk_all + (size_t)(t + 1) * slab + blk_offset(row, uq, H);
+      bf16_t* hdst = h_blk_all + slot_out * slab + blk_offset(row, uq, H);
       if (local) store_plain_b64(hdst, hn);
       else store_wt_b64(hdst, hn);
       if (gates != nullptr) {
@@ -389,10 +479,10 @@ __global__ void __launch_bounds__(256) lstm_fwd_persist_kernel(PersistFwdArgs a)
     // H = 512 instantiation return stale rows with it and correct ones without it: whatever the cause -- store
     // acknowledgements of different kinds overtaking each other, or compiler-placed spill traffic in the count --
     // the hand-off may not depend on it.  Full drain.)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (!dpoll) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     CSN_PSTAMP(4);     // drain + barrier
-    if (tid == 0) {
+    if (!dpoll && tid == 0) {
       unsigned* fl = flags + (size_t)(t + 1) * flag_step + slice;
       // L2-local groups: a plain store, kept in the one L2 all readers poll; otherwise written through
       if (local) *fl = 1u;
@@ -425,10 +515,12 @@ int fwd_persist_slices(int H) { return H / (4 * ((H % 24 == 0) ? 6 : 8)); }
 template <int NQ, int KS>
 static int launch_persist_t(const PersistFwdArgs& a, hipStream_t st) {
   const size_t lds = (size_t)(4 * 4 * NQ * 65 + 4 * NQ) * sizeof(float4);
-  if (int rc = ensure_dyn_lds<&lstm_fwd_persist_kernel<NQ, KS>>((int)lds)) return rc;
+  if (int rc = ensure_dyn_lds<&lstm_fwd_persist_kernel<NQ, KS, false>>((int)lds)) return rc;
+  if (int rc = ensure_dyn_lds<&lstm_fwd_persist_kernel<NQ, KS, true>>((int)lds)) return rc;
   const unsigned nslices = (unsigned)(a.H / (4 * NQ));
   const unsigned grid = a.xcd_groups ? 8u * nslices : nslices * (unsigned)(a.MT * a.nslots);
-  lstm_fwd_persist_kernel<NQ, KS><<<dim3(grid), 256, lds, st>>>(a);
+  if (a.data_polls) lstm_fwd_persist_kernel<NQ, KS, true><<<dim3(grid), 256, lds, st>>>(a);
+  else lstm_fwd_persist_kernel<NQ, KS, false><<<dim3(grid), 256, lds, st>>>(a);
   CSN_LAUNCH_CHECK();
   return CSN_OK;
 }

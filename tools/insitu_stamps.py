@@ -36,6 +36,8 @@ for it in range(4):
         per = [buf[i] * 0.01 / T for i in range(6)]
         if sum(buf[i] for i in range(7)) == 0:
             continue
+        if name == "bwd" and any(buf[8 + i] for i in range(4)):
+            print("   bwd data polls: MFMA phases redone per wave (all workgroups, this training step):", [int(buf[8 + i]) for i in range(4)])
         if name == "fwd-nsplit":
             print("   nsplit detail per-step us: dma issue %.2f | x-mfma + input request %.2f | wait g0 %.2f | g0 mfma + wait g1 %.2f | g1,g2 mfma + waits %.2f | (g3 mfma in loads+mfma rest)"
                   % tuple(buf[i] * 0.01 / T for i in (8, 9, 10, 11, 12)))
