@@ -257,9 +257,6 @@ __global__ void __launch_bounds__(256) lstm_bwd_persist_kernel(PersistBwdArgs a)
           }
         }
       }
-#ifdef CSN_BWD_SETTLE
-      if constexpr (dpoll) __builtin_amdgcn_s_sleep(CSN_BWD_SETTLE);      // (experiment: let the producers' other pieces land)
-#endif
       CSN_BSTAMP(0);   // wait for dgates_{t+1}
       const __amdgpu_buffer_rsrc_t slabs_rsrc = dpoll ? ring_rsrc : __builtin_amdgcn_make_buffer_rsrc(
           (void*)(dg_blk_all + (size_t)(t + 1) * slab), 0, slab_bytes, 0x00020000);
@@ -267,9 +264,7 @@ __global__ void __launch_bounds__(256) lstm_bwd_persist_kernel(PersistBwdArgs a)
       // (the k-block walk offset re-enters the step as an opaque scalar: left visible as a loop invariant, the compiler
       // keeps the 24 rotated block offsets of every load in SGPRs across the steps and runs out of them)
       int rot_t = rot;
-#if !defined(CSN_BWD_ABL) || CSN_BWD_ABL != 3
-      if constexpr (dpoll) asm volatile("" : "+s"(rot_t));
-#endif
+      asm volatile("" : "+s"(rot_t));
       const unsigned base = (unsigned)((((size_t)(m0 >> 4) * kblocks + ks_beg) * 512 + lane * 8) * 2);
       // ring of RING k-blocks: issue order = consumption order (pinned), so the MFMAs of a k-block wait only
       // for its own 4 loads while the next RING-1 k-blocks are in flight.
@@ -322,11 +317,7 @@ __global__ void __launch_bounds__(256) lstm_bwd_persist_kernel(PersistBwdArgs a)
           for (int rg = 0; rg < 4; ++rg)
 #pragma unroll
             for (int ut = 0; ut < NUT; ++ut) chk += (acc[rg][ut][0] + acc[rg][ut][1]) + (acc[rg][ut][2] + acc[rg][ut][3]);
-#if defined(CSN_BWD_ABL) && CSN_BWD_ABL == 2
-          if (false) {
-#else
           if (__builtin_expect(!__all(chk == chk), 0)) {
-#endif
 #ifdef CSN_PSTAMPS
             if (lane == 0) atomicAdd(&g_bstamps[8 + wave], 1ull);        // (diagnostic: phases redone, per wave, all workgroups)
 #endif
@@ -356,7 +347,6 @@ __global__ void __launch_bounds__(256) lstm_bwd_persist_kernel(PersistBwdArgs a)
     // data polls: re-arm slot (t - 2) & 3 (it holds dgates_{t+2}: every producer has published dgates_{t+1}, so all of
     // them have read it; it is looked at again at step t-3, after this workgroup's dgates_{t-1} was consumed, which
     // is stored behind loads that retire these stores -- the argument of lstm_fwd_persist.hip, mirrored in time)
-#if !defined(CSN_BWD_ABL) || CSN_BWD_ABL != 1
     if (dpoll) {
       const int arm_off = __builtin_amdgcn_readfirstlane(((t + 2) & 3) * slab_bytes);
       const bf16x8 sent = __builtin_bit_cast(bf16x8, (u32x4){0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu});
@@ -374,7 +364,6 @@ __global__ void __launch_bounds__(256) lstm_bwd_persist_kernel(PersistBwdArgs a)
       }
       __builtin_amdgcn_sched_barrier(0);
     }
-#endif
 
     const __amdgpu_buffer_rsrc_t slabs_rsrc = dpoll ? ring_rsrc : __builtin_amdgcn_make_buffer_rsrc(
         (void*)(dg_blk_all + (size_t)t * slab), 0, slab_bytes, 0x00020000);
