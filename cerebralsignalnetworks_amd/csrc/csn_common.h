@@ -48,7 +48,7 @@ int fail(int status, const char* fmt, ...);
 // library keeps no mutable global state, so plans on different streams / threads / devices never share any.
 struct Options {
   bool cell_v1, no_persist, no_persist_bwd, persist_streams, no_xcd_local, no_rotate, no_fuse_x, no_beside,
-      no_side_stream, gemm_slot, fwd_ksplit, fwd_nsplit, fwd_halves, fwd_ws, fwd_flags, bwd_flags, dpoll_no_hint, beside_fwd, xproj_bf16, wgrad_overlap, gemm_no_dma, gemm_no_256, gemm_generic, gemm_lds64, tn_no_tr, tn_no_stagger, filter_v1;
+      no_side_stream, gemm_slot, fwd_ksplit, fwd_nsplit, fwd_halves, fwd_ws, fwd_flags, bwd_flags, dpoll_no_hint, fwd_hint, beside_fwd, xproj_bf16, wgrad_overlap, gemm_no_dma, gemm_no_256, gemm_generic, gemm_lds64, tn_no_tr, tn_no_stagger, filter_v1;
   int chunk;       // timesteps per weight-stationary launch
   int tn_stages;   // LDS-DMA ring depth of the 256 x 256 weight-gradient kernel
   int fwd_nk;
@@ -77,6 +77,7 @@ static inline Options options_from_env() {
   o.fwd_flags = on("CSN_FWD_FLAGS");
   o.bwd_flags = on("CSN_BWD_FLAGS");
   o.dpoll_no_hint = on("CSN_DPOLL_NO_HINT");
+  o.fwd_hint = on("CSN_FWD_HINT");
   o.tn_no_stagger = on("CSN_TN_NO_STAGGER");
   o.beside_fwd = on("CSN_BESIDE_FWD");
   o.xproj_bf16 = on("CSN_XPROJ_BF16");

@@ -516,11 +516,13 @@ def test_fast_path_matches_oracle_and_v1(cuda, B, T, C, H, L, chunk):
     # wgrad_beside: the upper layers' weight-gradient GEMMs beside the last backward launches on the plan's
     # low-priority stream instead of after the recurrence on the caller's stream -- slower, kept as a switch)
     # (flags: the hand-off of round 1 -- drained stores, one flag word per workgroup and step -- instead of the data
-    # polls on a ring of 4 sentinel-armed slabs; nohint: the data polls without their hint words, so that EVERY step
-    # loads before its operands are there and goes through the re-read paths)
+    # polls on a ring of 4 sentinel-armed slabs; nohint: the data polls without hint words in the backward too (the
+    # forward's default), so that EVERY step loads before its operands are there and goes through the re-read / redo
+    # paths; fwd hint: the forward with hint words)
     for name, other in (("serial", run(CSN_NO_SIDE_STREAM="1")), ("anyplace", run(CSN_NO_XCD_LOCAL="1")),
                         ("nobeside", run(CSN_NO_BESIDE="1")), ("wgrad_beside", run(CSN_WGRAD_OVERLAP="1")),
                         ("flags", run(CSN_FWD_FLAGS="1", CSN_BWD_FLAGS="1")), ("nohint", run(CSN_DPOLL_NO_HINT="1")),
+                        ("fwd hint", run(CSN_FWD_HINT="1")),
                         ("nohint anyplace", run(CSN_DPOLL_NO_HINT="1", CSN_NO_XCD_LOCAL="1"))):
         for k in fast:
             _assert_same_bits(fast[k], other[k], f"{name}: {k}")
