@@ -133,10 +133,16 @@ __global__ void __launch_bounds__(256) prep_multi_kernel(PrepArgs A) {
         const int64_t r = (blk / kblocks) * 16 + (lane & 15), k = (blk % kblocks) * 32 + 8 * (lane >> 4);
         const int64_t rs = J.perm_r ? std_row(r, H) : r;
         bf16x8 v;
+        if (!J.perm_k && ld_k == 1 && (ld_r & 3) == 0) {        // the 8 elements are contiguous in the source: two 16-byte loads
+          const float4* sp = reinterpret_cast<const float4*>(J.a + rs * ld_r + k);
+          const float4 u = sp[0], w = sp[1];
+          v = (bf16x8){(bf16_t)u.x, (bf16_t)u.y, (bf16_t)u.z, (bf16_t)u.w, (bf16_t)w.x, (bf16_t)w.y, (bf16_t)w.z, (bf16_t)w.w};
+        } else {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const int64_t ks = J.perm_k ? std_row(k + e, H) : (k + e);
-          v[e] = (bf16_t)J.a[rs * ld_r + ks * ld_k];
+          for (int e = 0; e < 8; ++e) {
+            const int64_t ks = J.perm_k ? std_row(k + e, H) : (k + e);
+            v[e] = (bf16_t)J.a[rs * ld_r + ks * ld_k];
+          }
         }
         *reinterpret_cast<bf16x8*>(dst + ci * 8) = v;
       }
@@ -145,7 +151,17 @@ __global__ void __launch_bounds__(256) prep_multi_kernel(PrepArgs A) {
     case kPrepPermRows: {                 // dst[n'][i] = src[std_row(n')][i]
       const int64_t H = J.H, I = J.n1;
       bf16_t* dst = (bf16_t*)J.dst;
-      for (int64_t i = gid; i < 4 * H * I; i += stride) dst[i] = (bf16_t)J.a[std_row(i / I, H) * I + i % I];
+      if ((I & 7) == 0) {                   // 8 elements per thread and trip: two 16-byte loads, one 16-byte store
+        for (int64_t c = gid; c < 4 * H * I / 8; c += stride) {
+          const int64_t i = c * 8;
+          const float4* sp = reinterpret_cast<const float4*>(J.a + std_row(i / I, H) * I + i % I);
+          const float4 u = sp[0], v = sp[1];
+          *reinterpret_cast<bf16x8*>(dst + i) = (bf16x8){(bf16_t)u.x, (bf16_t)u.y, (bf16_t)u.z, (bf16_t)u.w,
+                                                         (bf16_t)v.x, (bf16_t)v.y, (bf16_t)v.z, (bf16_t)v.w};
+        }
+      } else {
+        for (int64_t i = gid; i < 4 * H * I; i += stride) dst[i] = (bf16_t)J.a[std_row(i / I, H) * I + i % I];
+      }
       break;
     }
     case kPrepTransPerm: {                // dst[i][n'] = src[std_row(n')][i]
@@ -162,9 +178,19 @@ __global__ void __launch_bounds__(256) prep_multi_kernel(PrepArgs A) {
     case kPrepCastX: {                    // x[b][t][i] (strides s0, s1) -> time-major [T][B][I] bf16
       const int64_t Bn = J.n0, Tn = J.n1, I = J.n2;
       bf16_t* dst = (bf16_t*)J.dst;
-      for (int64_t i = gid; i < Bn * Tn * I; i += stride) {
-        const int64_t i2 = i % I, r = i / I, b = r % Bn, t = r / Bn;
-        dst[i] = (bf16_t)J.a[b * J.s0 + t * J.s1 + i2];
+      if ((I & 7) == 0 && (J.s0 & 3) == 0 && (J.s1 & 3) == 0 && (reinterpret_cast<uintptr_t>(J.a) & 15) == 0) {
+        for (int64_t c = gid; c < Bn * Tn * I / 8; c += stride) {     // 8 elements per thread and trip
+          const int64_t i = c * 8, i2 = i % I, r = i / I, b = r % Bn, t = r / Bn;
+          const float4* sp = reinterpret_cast<const float4*>(J.a + b * J.s0 + t * J.s1 + i2);
+          const float4 u = sp[0], v = sp[1];
+          *reinterpret_cast<bf16x8*>(dst + i) = (bf16x8){(bf16_t)u.x, (bf16_t)u.y, (bf16_t)u.z, (bf16_t)u.w,
+                                                         (bf16_t)v.x, (bf16_t)v.y, (bf16_t)v.z, (bf16_t)v.w};
+        }
+      } else {
+        for (int64_t i = gid; i < Bn * Tn * I; i += stride) {
+          const int64_t i2 = i % I, r = i / I, b = r % Bn, t = r / Bn;
+          dst[i] = (bf16_t)J.a[b * J.s0 + t * J.s1 + i2];
+        }
       }
       break;
     }
@@ -175,8 +201,14 @@ __global__ void __launch_bounds__(256) prep_multi_kernel(PrepArgs A) {
         const int64_t t = ci / per_t, c = ci % per_t, blk = c >> 6, lane = c & 63;
         const int64_t r = (blk / kblocks) * 16 + (lane & 15), k = (blk % kblocks) * 32 + 8 * (lane >> 4);
         bf16x8 v;
+        if (r < Bn && ((J.s0 | J.s1) & 3) == 0 && (reinterpret_cast<uintptr_t>(J.a) & 15) == 0) {
+          const float4* sp = reinterpret_cast<const float4*>(J.a + r * J.s0 + t * J.s1 + k);
+          const float4 u = sp[0], w = sp[1];
+          v = (bf16x8){(bf16_t)u.x, (bf16_t)u.y, (bf16_t)u.z, (bf16_t)u.w, (bf16_t)w.x, (bf16_t)w.y, (bf16_t)w.z, (bf16_t)w.w};
+        } else {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = (bf16_t)(r < Bn ? J.a[r * J.s0 + t * J.s1 + k + e] : 0.f);
+          for (int e = 0; e < 8; ++e) v[e] = (bf16_t)(r < Bn ? J.a[r * J.s0 + t * J.s1 + k + e] : 0.f);
+        }
         *reinterpret_cast<bf16x8*>(dst + ci * 8) = v;
       }
       break;
