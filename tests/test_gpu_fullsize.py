@@ -176,6 +176,33 @@ def test_timed_out_handoff_in_an_early_step_is_still_reported(cuda):
     tr.check_device_status()                      # reported once, then cleared: training can go on
 
 
+def test_nan_in_the_backward_is_reported_not_hung(cuda):
+    """With the hand-off by data a NaN in dgates looks like an operand that never arrives (the sentinel is a pair of
+    bf16 NaNs): it must end as ONE bounded wait and a raised status word -- no hang, no per-step stall -- and a NaN in
+    the forward's h (an arithmetic NaN, not the sentinel pattern) must not stall the forward at all."""
+    import time
+    from cerebralsignalnetworks_amd.trainer import DistillTrainer
+    rng = np.random.default_rng(1)
+    B, C, T, H, D = 64, 32, 40, 128, 16
+    m = Model(input_size=C, lstm_size=H, lstm_layers=2, output_size=D, include_top=False).to(cuda)
+    tr = DistillTrainer(m, None, loss="cosine")
+    x = torch.from_numpy(rng.standard_normal((B, C, T)).astype(np.float32)).to(cuda)
+    tg = torch.from_numpy(rng.standard_normal((B, D)).astype(np.float32)).to(cuda)
+    tr.train_step(x, tg)
+    tr.check_device_status()
+    x_bad = x.clone()
+    x_bad[3, :, 7] = float("nan")                      # one NaN sample: h of that row is NaN from step 7 on
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    loss = tr.train_step(x_bad, tg)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    assert elapsed < 5.0, elapsed                      # 2 layers x a few bounded waits of 0.2 s at most, not T of them
+    assert not np.isfinite(float(loss))
+    with pytest.raises(RuntimeError, match="timed out"):
+        tr.check_device_status()
+
+
 def test_plans_are_independent_across_streams_and_threads(cuda):
     """The library keeps no global state: two plans driven from two host threads on two HIP streams at the same
     time give the bits each gives alone (side streams, event pools and profiling events are per plan)."""
