@@ -44,7 +44,16 @@ namespace csn {
 
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
-static constexpr unsigned long long kBwdSpinTimeoutTicks = 20000000ull;   // 0.2 s of the 100 MHz wall clock
+static constexpr unsigned long long kBwdSpinTimeoutTicks = 20000000ull;
+
+// Reduction buffer: float4 slot of (batch row r of the 16-row group, unit q of the 4-unit tile) inside an accumulator
+// tile.  The accumulator layout would put it at r + 16 q -- but the epilogue's 16-lane groups are 2 consecutive rows x
+// 8 unit quads (2 tiles x 4 units), and r + 16 q puts the 4 units of a row on ONE 16-byte bank group (16 float4 = one
+// turn of the 64 banks), the two tiles one group apart: eight lanes on the same group.  pi(r) + 17 q with
+// pi(r) = r / 2 + 8 (r mod 2) and a tile pitch of 4 mod 16 gives the 16 lanes 16 different groups, and a writing
+// 16-lane group (q fixed, r = 0..15) as well.
+static constexpr int kBwdRedTile = 68;
+__device__ __forceinline__ int bwd_red_pos(int r, int q) { return (r >> 1) + 8 * (r & 1) + 17 * q; }   // 0.2 s of the 100 MHz wall clock
 
 typedef __attribute__((ext_vector_type(4))) unsigned bu32x4;
 
@@ -69,7 +78,7 @@ __global__ void __launch_bounds__(256) lstm_bwd_persist_kernel(PersistBwdArgs a)
   constexpr int NPAIR = 64 * QPR;                // (row, unit-quad) pairs
   constexpr int NPASS = NPAIR / 256;
   static_assert(NPAIR % 256 == 0, "tile must split evenly over the 256 threads");
-  extern __shared__ __attribute__((aligned(16))) float4 red[];   // [4][NT][65]
+  extern __shared__ __attribute__((aligned(16))) float4 red[];   // [4][NT][kBwdRedTile]
   const int B = a.B, H = a.H, MT = a.MT, T = a.T;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #ifdef CSN_PSTAMPS
@@ -340,7 +349,7 @@ __global__ void __launch_bounds__(256) lstm_bwd_persist_kernel(PersistBwdArgs a)
     for (int rg = 0; rg < 4; ++rg)
 #pragma unroll
       for (int ut = 0; ut < NUT; ++ut)
-        red[(wave * NT + rg * NUT + ut) * 65 + lane] = make_float4(acc[rg][ut][0], acc[rg][ut][1], acc[rg][ut][2], acc[rg][ut][3]);
+        red[(wave * NT + rg * NUT + ut) * kBwdRedTile + bwd_red_pos(lane & 15, lane >> 4)] = make_float4(acc[rg][ut][0], acc[rg][ut][1], acc[rg][ut][2], acc[rg][ut][3]);
     __syncthreads();
     CSN_BSTAMP(2);     // LDS write + barrier
 
@@ -386,11 +395,11 @@ __global__ void __launch_bounds__(256) lstm_bwd_persist_kernel(PersistBwdArgs a)
         continue;
       }
       const int rl = prl[ps], jq = pjq[ps], row = prow[ps], uq = puq[ps];
-      const int idx = ((rl >> 4) * NUT + (jq >> 2)) * 65 + (rl & 15) + 16 * (jq & 3);
+      const int idx = ((rl >> 4) * NUT + (jq >> 2)) * kBwdRedTile + bwd_red_pos(rl & 15, jq & 3);
       float4 sm = red[idx];
 #pragma unroll
       for (int w2 = 1; w2 < 4; ++w2) {
-        const float4 v = red[w2 * NT * 65 + idx];
+        const float4 v = red[w2 * NT * kBwdRedTile + idx];
         sm.x += v.x; sm.y += v.y; sm.z += v.z; sm.w += v.w;
       }
       const float dh[4] = {sm.x + dyv[ps].x, sm.y + dyv[ps].y, sm.z + dyv[ps].z, sm.w + dyv[ps].w};
@@ -456,7 +465,7 @@ int bwd_persist_slices(int H) { return H / 32; }
 
 template <int NUT, int KS>
 static int launch_bwd_persist_t(const PersistBwdArgs& a, hipStream_t st) {
-  size_t lds = (size_t)4 * 4 * NUT * 65 * sizeof(float4);
+  size_t lds = (size_t)4 * 4 * NUT * kBwdRedTile * sizeof(float4);
   if (int rc = ensure_dyn_lds<&lstm_bwd_persist_kernel<NUT, KS, false>>((int)kBesideLdsBytes + 64)) return rc;
   if (int rc = ensure_dyn_lds<&lstm_bwd_persist_kernel<NUT, KS, true>>((int)kBesideLdsBytes + 64)) return rc;
   const unsigned nslices = (unsigned)(a.H / (16 * NUT));

@@ -63,6 +63,10 @@ __device__ unsigned long long g_pstamps[8];
 
 namespace csn {
 
+// float4 slots per accumulator tile in the reduction buffer: 64 + padding.  The epilogue's lanes walk (row, unit quad j)
+// with j fastest and read slot (tile j, row): with 65 a lane's 16-byte bank group is (j + row) mod 16 -- three lanes of a
+// 16-lane group on one group; with 71 it is (7 j + row) mod 16, distinct except for one rare pair.
+static constexpr int kRedTile = 71;
 static constexpr unsigned long long kSpinTimeoutTicks = 20000000ull;   // 0.2 s of the 100 MHz wall clock
 
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
@@ -110,7 +114,7 @@ __global__ void __launch_bounds__(256) lstm_fwd_persist_kernel(PersistFwdArgs a)
   constexpr int NT = 4 * NQ;
   constexpr int NPAIR = 64 * NQ;
   constexpr int NPASS = (NPAIR + 255) / 256;
-  extern __shared__ __attribute__((aligned(16))) float4 red[];   // [4][NT][65], then [NQ][4] bias
+  extern __shared__ __attribute__((aligned(16))) float4 red[];   // [4][NT][kRedTile], then [NQ][4] bias
   const int B = a.B, H = a.H, MT = a.MT;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #ifdef CSN_PSTAMPS
@@ -192,7 +196,7 @@ __global__ void __launch_bounds__(256) lstm_fwd_persist_kernel(PersistFwdArgs a)
   f32x4 cur[8], nxt[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) cur[i] = nxt[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  float* const bias_lds = reinterpret_cast<float*>(red + 4 * NT * 65);      // [NQ][4] float4, behind the reduction buffer
+  float* const bias_lds = reinterpret_cast<float*>(red + 4 * NT * kRedTile);      // [NQ][4] float4, behind the reduction buffer
   if (fused) {
     if (xwave) {
 #pragma unroll
@@ -394,7 +398,7 @@ __global__ void __launch_bounds__(256) lstm_fwd_persist_kernel(PersistFwdArgs a)
     for (int rg = 0; rg < 4; ++rg)
 #pragma unroll
       for (int j = 0; j < NQ; ++j)
-        red[(wave * NT + rg * NQ + j) * 65 + lane] = make_float4(acc[rg][j][0], acc[rg][j][1], acc[rg][j][2], acc[rg][j][3]);
+        red[(wave * NT + rg * NQ + j) * kRedTile + lane] = make_float4(acc[rg][j][0], acc[rg][j][1], acc[rg][j][2], acc[rg][j][3]);
     __syncthreads();
     CSN_PSTAMP(2);     // LDS write + barrier
 
@@ -440,11 +444,11 @@ __global__ void __launch_bounds__(256) lstm_fwd_persist_kernel(PersistFwdArgs a)
       const float cpv[4] = {cst[ps].x, cst[ps].y, cst[ps].z, cst[ps].w};
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const int idx = ((rl >> 4) * NQ + j) * 65 + (rl & 15) + 16 * q;
+        const int idx = ((rl >> 4) * NQ + j) * kRedTile + (rl & 15) + 16 * q;
         float4 sum = red[idx];
 #pragma unroll
         for (int w2 = 1; w2 < 4; ++w2) {
-          const float4 v = red[w2 * NT * 65 + idx];
+          const float4 v = red[w2 * NT * kRedTile + idx];
           sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
         }
         const f32x4 xq = fused ? (f32x4){0.f, 0.f, 0.f, 0.f} : cur[ps * 4 + q];
@@ -514,7 +518,7 @@ int fwd_persist_slices(int H) { return H / (4 * ((H % 24 == 0) ? 6 : 8)); }
 
 template <int NQ, int KS>
 static int launch_persist_t(const PersistFwdArgs& a, hipStream_t st) {
-  const size_t lds = (size_t)(4 * 4 * NQ * 65 + 4 * NQ) * sizeof(float4);
+  const size_t lds = (size_t)(4 * 4 * NQ * kRedTile + 4 * NQ) * sizeof(float4);
   if (int rc = ensure_dyn_lds<&lstm_fwd_persist_kernel<NQ, KS, false>>((int)lds)) return rc;
   if (int rc = ensure_dyn_lds<&lstm_fwd_persist_kernel<NQ, KS, true>>((int)lds)) return rc;
   const unsigned nslices = (unsigned)(a.H / (4 * NQ));
