@@ -72,7 +72,10 @@ __device__ __forceinline__ void bstore_b128(__amdgpu_buffer_rsrc_t rsrc, unsigne
 
 template <int NUT, int KS, bool DPOLL>
 __global__ void __launch_bounds__(256) lstm_bwd_persist_kernel(PersistBwdArgs a) {
-  constexpr int RING = KS >= 32 ? 3 : (KS < 5 ? KS : 5);   // k-blocks of dgates in flight per wave (3 at H = 1024: register budget)
+#ifndef CSN_BWD_RING
+#define CSN_BWD_RING 5
+#endif
+  constexpr int RING = KS >= 32 ? 3 : (KS < CSN_BWD_RING ? KS : CSN_BWD_RING);   // k-blocks of dgates in flight per wave (3 at H = 1024: register budget)
   constexpr int NT = 4 * NUT;                    // accumulator tiles per wave (4 row groups x NUT unit tiles)
   constexpr int QPR = 4 * NUT;                   // unit quads per row of the tile
   constexpr int NPAIR = 64 * QPR;                // (row, unit-quad) pairs
