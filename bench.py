@@ -26,8 +26,8 @@ sys.path.insert(0, ROOT)
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16, MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
 HBM_PEAK_GBS = 8000.0            # HBM3E spec, same guide
-PMC_TRAFFIC_FILE = "r02_j_pmc_traffic.json"      # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/pmc_traffic.sh)
-PMC_COUNTERS_FILE = "r02_j_pmc_counters.json"    # MFMA-busy / wait / L2-hit / LDS-conflict passes (tools/pmc_counters.sh)
+PMC_TRAFFIC_FILE = "r02_k_pmc_traffic.json"      # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/pmc_traffic.sh)
+PMC_COUNTERS_FILE = "r02_k_pmc_counters.json"    # MFMA-busy / wait / L2-hit / LDS-conflict passes (tools/pmc_counters.sh)
 
 
 def parse():
