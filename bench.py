@@ -26,11 +26,74 @@ sys.path.insert(0, ROOT)
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16, MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
 HBM_PEAK_GBS = 8000.0            # HBM3E spec, same guide
-PMC_TRAFFIC_FILE = "r02_k_pmc_traffic.json"      # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/pmc_traffic.sh)
-PMC_COUNTERS_FILE = "r02_k_pmc_counters.json"    # MFMA-busy / wait / L2-hit / LDS-conflict passes (tools/pmc_counters.sh)
+PMC_TRAFFIC_FILE = "r03_pmc_traffic.json"      # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/pmc_traffic.sh)
+PMC_COUNTERS_FILE = "r03_pmc_counters.json"    # MFMA-busy / wait / L2-hit / LDS-conflict passes (tools/pmc_counters.sh)
 
 
-def parse():
+def csrc_sha16():
+    """Fingerprint of the kernel sources; the committed PMC passes record the one they were collected with."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "cerebralsignalnetworks_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.h"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def seeded_params(C, H, L, D, seed=43):
+    """= oracle.lstm.init_params(seed=43) (the weights every fixture under tests/golden was made with), restated:
+    the oracle is test infrastructure and is not imported by the measured path."""
+    rng = np.random.default_rng(seed)
+    k = 1.0 / np.sqrt(H)
+    sd = {}
+    for l in range(L):
+        i_sz = C if l == 0 else H
+        sd[f"lstm.weight_ih_l{l}"] = rng.uniform(-k, k, (4 * H, i_sz)).astype(np.float32)
+        sd[f"lstm.weight_hh_l{l}"] = rng.uniform(-k, k, (4 * H, H)).astype(np.float32)
+        sd[f"lstm.bias_ih_l{l}"] = rng.uniform(-k, k, (4 * H,)).astype(np.float32)
+        sd[f"lstm.bias_hh_l{l}"] = rng.uniform(-k, k, (4 * H,)).astype(np.float32)
+    sd["fc.weight"] = rng.uniform(-k, k, (D, H)).astype(np.float32)
+    sd["fc.bias"] = rng.uniform(-k, k, (D,)).astype(np.float32)
+    return {n: torch.from_numpy(v) for n, v in sd.items()}
+
+
+def fixture_parity(tag, device):
+    """|distill loss - the reference's| for the exact-f32 path and the benchmarked bf16 path, on the committed fixture
+    of the reference's own LSTMModel + CosineSimilarityLoss (tests/golden/ref_lstm_<tag>.npz: 8 segments, torch CPU
+    f64 / f32); batch 256 = 32 copies of the 8 segments, so the kernels and the launch shapes are the timed ones."""
+    from cerebralsignalnetworks_amd import Model, CosineSimilarityLoss
+    from cerebralsignalnetworks_amd.trainer import check_device_status
+    g = np.load(os.path.join(ROOT, "tests", "golden", f"ref_lstm_{tag}.npz"), allow_pickle=False)
+    B8, T, C, H, L, D = (int(v) for v in g["dims"])
+    rng = np.random.default_rng(int(g["seed_x"]))
+    x8 = rng.standard_normal((B8, T, C)).astype(np.float32)
+    t8 = rng.standard_normal((B8, D)).astype(np.float32)
+    x = torch.from_numpy(np.tile(x8, (32, 1, 1))).to(device)
+    tg = torch.from_numpy(np.tile(t8, (32, 1))).to(device)
+    sd = seeded_params(C, H, L, D, int(g["seed_params"]))
+    out = {"fixture": f"tests/golden/ref_lstm_{tag}.npz (reference LSTMModel + CosineSimilarityLoss, torch CPU)",
+           "loss_reference_f64": float(g["loss_f64"]), "loss_reference_f32": float(g["loss_f32"])}
+    for name, dt in (("f32", torch.float32), ("bf16", torch.bfloat16)):
+        m = Model(input_size=C, lstm_size=H, lstm_layers=L, output_size=D, include_top=False, compute_dtype=dt)
+        m.load_state_dict(sd)
+        m = m.to(device)
+        feat = m(x)
+        loss = CosineSimilarityLoss()(feat, tg)
+        loss.backward()
+        check_device_status(m)
+        gn = float(m.lstm.weight_hh_l0.grad.double().norm())
+        out[name] = {"loss": float(loss.item()), "abs_err_vs_f64": abs(float(loss.item()) - float(g["loss_f64"])),
+                     "feat_max_abs_err": float(np.abs(feat.detach().cpu().numpy()[:B8] - g["feat_f64"]).max()),
+                     "grad_norm_rel_err_w_hh_l0": abs(gn - float(g["gnorm__lstm.weight_hh_l0"])) / float(g["gnorm__lstm.weight_hh_l0"])}
+        del m, feat, loss
+    out["f32_within_1e-4"] = out["f32"]["abs_err_vs_f64"] < 1e-4
+    torch.cuda.empty_cache()
+    return out
+
+
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -48,8 +111,56 @@ def parse():
     ap.add_argument("--no-retrieval", action="store_true", help="skip the bf16-vs-CPU-reference retrieval acceptance")
     ap.add_argument("--no-f32-line", action="store_true", help="skip the short measurement of the exact-f32 path")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="skip the fixture check of the f32 / bf16 loss before the timed region")
     ap.add_argument("--no-kernel-timing", action="store_true")
-    return ap.parse_args()
+    return ap.parse_args(argv)
+
+
+def launcher_command(n_gpus, argv, port=None):
+    """argv + environment of the child job that runs N ranks of this file, one per GPU (the shape of the reference's
+    own launch, EEG-BarlowNetworks/train.py:71,76-78: one worker per GPU, rank = GPU index, tcp rendezvous on the
+    loopback address).  The parent that calls this never touches the GPU."""
+    import socket
+    if port is None:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on these hosts (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "4")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    return cmd, env
+
+
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` without a launcher around it: start N fresh rank processes and relay rank 0's line.
+    Nothing here initialises HIP (device_count() does not on this image); the children are new processes, not an
+    exec of this one."""
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < args.gpus and not os.environ.get("CSN_SINGLE_DEVICE"):
+        print(f"bench.py: --gpus {args.gpus} asked for but this host shows {have} GPU(s); refusing to report a "
+              f"{args.gpus}-GPU number from fewer devices", file=sys.stderr)
+        return 2
+    cmd, env = launcher_command(args.gpus, argv)
+    log("launcher: " + " ".join(cmd))
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
+    for ln in proc.stdout.splitlines():
+        if not ln.startswith("{"):
+            print(ln, file=sys.stderr)
+    if proc.returncode != 0 or len(lines) != 1:
+        print(f"bench.py: the {args.gpus}-rank job exited with {proc.returncode} and {len(lines)} result line(s)",
+              file=sys.stderr)
+        return proc.returncode or 3
+    if json.loads(lines[0]).get("n_gpus") != args.gpus:
+        print("bench.py: result line does not carry the requested rank count", file=sys.stderr)
+        return 4
+    print(lines[0], flush=True)
+    return 0
 
 
 def synthetic_pool(n, C, T, D, rank, device):
@@ -66,16 +177,17 @@ def log(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
-def retrieval_acceptance(model_bf16, filt, device):
+def retrieval_acceptance(model_bf16, filt, device, tag="cfg2"):
     """North star: 'retrieval top-1 within +-0.5 % of the CPU reference'.  The seeded clustered set (2048 gallery /
     512 query, 40 classes) is embedded with the benchmarked bf16 path (HIP filter -> HIP LSTM) and searched with
     csn_l2_topk; the CPU reference's neighbour lists for the same set and the same weights (scipy sosfilt + z-score ->
     the reference's LSTMModel on torch CPU f32, made by tests/golden/make_ref_goldens.py) are a committed fixture."""
     from cerebralsignalnetworks_amd import cabi
     from cerebralsignalnetworks_amd.dataset import clustered_eeg
-    g = np.load(os.path.join(ROOT, "tests", "golden", "ref_retrieval_cfg2.npz"), allow_pickle=False)
+    g = np.load(os.path.join(ROOT, "tests", "golden", f"ref_retrieval_{tag}.npz"), allow_pickle=False)
     ng, nq = int(g["n_gallery"]), int(g["n_query"])
-    x, labels = clustered_eeg(ng + nq, seed=int(g["seed"]), snr=float(g["snr"]))
+    T = int(g["dims"][1]) if "dims" in g.files else 500
+    x, labels = clustered_eeg(ng + nq, T=T, seed=int(g["seed"]), snr=float(g["snr"]))
     outs = []
     with torch.no_grad():
         for i in range(0, ng + nq, 256):
@@ -95,7 +207,14 @@ def main():
     args = parse()
     if args.config == "cfg4":      # LstmDistillFromDinoV2TrainSpampinato.py:368 shapes (BASELINE.json configs[3])
         args.samples, args.hidden = 440, 1024
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
+              f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...)",
+              file=sys.stderr)
+        sys.exit(2)
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if os.environ.get("CSN_SINGLE_DEVICE"):      # rehearsal of the multi-rank path on a one-GPU box
@@ -122,6 +241,11 @@ def main():
     filt = EEGFilters(1000, order=3)
     trainer = DistillTrainer(model, filt.sos, loss="cosine", lr=1e-3, optimizer="rmsprop")
     x, tg, lab = synthetic_pool(B * args.pool, C, T, D, rank, device)
+    parity = None
+    ptag = {(128, 500, 768, 2, 384): "cfg2", (128, 440, 1024, 2, 384): "cfg4"}.get((C, T, H, L, D))
+    if rank == 0 and ptag is not None and not args.no_parity:
+        log("parity: f32 and bf16 paths on the reference-made fixture (before the timed region)")
+        parity = fixture_parity(ptag, device)
 
     def step(i):
         j = (i % args.pool) * B
@@ -140,6 +264,8 @@ def main():
     t0 = time.perf_counter()
     loss = None
     step_losses = []
+    if world > 1:
+        trainer.grads.timing = []
     for i in range(args.steps):
         if i == args.steps - 1 and rank == 0 and not args.no_kernel_timing:
             # HIP events around every recurrence launch (same stream), in the LAST timed step only: recorded in
@@ -157,6 +283,25 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     final_loss = float(loss.item())
+    dp = None
+    if world > 1:
+        # proof that N ranks ran and stayed in step: every rank adds one; after K all-reduced steps from a broadcast
+        # start every rank must hold the same parameter bits (the checksum is an exact integer sum of the f32 words)
+        ones = torch.ones(1, device=device, dtype=torch.float64)
+        dist.all_reduce(ones)
+        pbuf = trainer.grads.flat_params if trainer.grads.flat_params is not None else torch.cat(
+            [p.detach().reshape(-1) for p in trainer.grads.params])
+        csum = pbuf.view(torch.int32).to(torch.int64).sum().reshape(1)
+        lo, hi = csum.clone(), csum.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        dp = {"ranks_seen": int(ones.item()), "param_checksum": int(csum.item()),
+              "param_checksum_equal_on_all_ranks": bool(lo.item() == hi.item()),
+              "allreduce_ms_per_step": trainer.grads.all_reduce_ms(), "allreduce_bytes": trainer.grads.flat.numel() * 4,
+              "backend": dist.get_backend(), "single_device_rehearsal": bool(os.environ.get("CSN_SINGLE_DEVICE"))}
+        if dp["ranks_seen"] != args.gpus or not dp["param_checksum_equal_on_all_ranks"]:
+            print(f"bench.py: rank {rank}: data-parallel check failed: {dp}", file=sys.stderr)
+            sys.exit(5)
     trainer.check_device_status()       # a timed-out in-kernel hand-off would invalidate the run: fail loudly
     log(f"timed region done: {elapsed:.3f}s for {args.steps} steps; losses " +
         " ".join(f"{float(l):.4f}" for l in step_losses))
@@ -178,6 +323,10 @@ def main():
             "final_loss": final_loss,
             "model_tflops": seg_per_s * flops_per_seg / 1e12,
         }
+        if dp is not None:
+            res["data_parallel"] = dp
+        if parity is not None:
+            res["parity"] = parity
         if not args.no_kernel_timing:
             # dominant kernel = the recurrence kernel with the larger total time in the step; its average launch
             # duration comes from HIP events recorded on the launch stream around its launches of the LAST timed step
@@ -208,22 +357,32 @@ def main():
             ach_gb = bytes_per_launch / t_launch / 1e9
             # the binding roofline is the one with the larger minimum time
             hbm_bound = bytes_per_launch / (HBM_PEAK_GBS * 1e9) >= flops_per_launch / (peak * 1e12)
-            traffic = mfma_util = None      # from the committed PMC passes of the same workload (profiles/)
+            # from the committed PMC passes of the same workload (profiles/): NOT measured in this run -- the source is
+            # named beside the values, and they are dropped when the kernel sources changed since the pass
+            traffic = mfma_util = None
+            traffic_source = None
             try:
                 if (B, C, T, H, L) != (256, 128, 500, 768, 2):
                     raise KeyError("PMC passes were collected for cfg2 only")
                 pmc = json.load(open(os.path.join(ROOT, "profiles", PMC_TRAFFIC_FILE)))
-                traffic = pmc["kernels"][kname]["hbm_bytes_per_launch_corrected"]
                 cnt = json.load(open(os.path.join(ROOT, "profiles", PMC_COUNTERS_FILE)))
-                mfma_util = cnt["kernels"][kname]["derived"]["mfma_util"]
-            except (OSError, KeyError, ValueError):
-                pass
+                now = csrc_sha16()
+                if pmc.get("csrc_sha16") != now or cnt.get("csrc_sha16") != now:
+                    traffic_source = (f"profiles/{PMC_TRAFFIC_FILE}, profiles/{PMC_COUNTERS_FILE}: STALE (collected with "
+                                      f"kernel sources {pmc.get('csrc_sha16')}, this build is {now}) -- values dropped")
+                else:
+                    traffic = pmc["kernels"][kname]["hbm_bytes_per_launch_corrected"]
+                    mfma_util = cnt["kernels"][kname]["derived"]["mfma_util"]
+                    traffic_source = (f"profiles/{PMC_TRAFFIC_FILE} + profiles/{PMC_COUNTERS_FILE}: committed rocprofv3 --pmc "
+                                      f"passes of this workload (kernel sources {now}); not measured in this run")
+            except (OSError, KeyError, ValueError) as e:
+                traffic_source = f"none ({e})"
             res["roofline"] = {"bound": "hbm" if hbm_bound else "mfma", "kernel": kname,
                                "achieved": ach_gb if hbm_bound else ach_tf,
                                "peak": HBM_PEAK_GBS if hbm_bound else peak,
                                "unit": "GB/s" if hbm_bound else "TFLOP/s",
                                "frac": (ach_gb / HBM_PEAK_GBS) if hbm_bound else (ach_tf / peak), "traffic": traffic,
-                               "mfma_util": mfma_util,
+                               "mfma_util": mfma_util, "traffic_source": traffic_source,
                                "algorithmic_bytes_per_launch": bytes_per_launch, "flops_per_launch": flops_per_launch,
                                "other_roofline": {"bound": "mfma" if hbm_bound else "hbm",
                                                   "achieved": ach_tf if hbm_bound else ach_gb,
@@ -233,25 +392,15 @@ def main():
                                "note": "recurrent GEMM chain with one hand-off between workgroups per timestep; neither "
                                        "roofline binds: the step is paced by the per-step operand stream from L2 and "
                                        "the hand-off latency (DESIGN.md section 3)"}
-        if world == 1 and args.dtype == "bf16" and (C, T, H, L, D) == (128, 500, 768, 2, 384) and not args.no_retrieval:
+        rtag = {(128, 500, 768, 2, 384): "cfg2", (128, 440, 1024, 2, 384): "cfg4"}.get((C, T, H, L, D))
+        if world == 1 and args.dtype == "bf16" and rtag is not None and not args.no_retrieval:
             # same architecture with the fixture's seeded weights (the timed model's weights have been trained on noise)
             from cerebralsignalnetworks_amd.trainer import check_device_status
             log("retrieval acceptance (bf16 path vs CPU-reference fixture)")
             rm = Model(input_size=C, lstm_size=H, lstm_layers=L, output_size=D, include_top=False, compute_dtype=dtype)
-            rng = np.random.default_rng(43)       # = oracle.lstm.init_params(seed=43), restated: the oracle is not imported here
-            k = 1.0 / np.sqrt(H)
-            sd = {}
-            for l in range(L):
-                i_sz = C if l == 0 else H
-                sd[f"lstm.weight_ih_l{l}"] = rng.uniform(-k, k, (4 * H, i_sz)).astype(np.float32)
-                sd[f"lstm.weight_hh_l{l}"] = rng.uniform(-k, k, (4 * H, H)).astype(np.float32)
-                sd[f"lstm.bias_ih_l{l}"] = rng.uniform(-k, k, (4 * H,)).astype(np.float32)
-                sd[f"lstm.bias_hh_l{l}"] = rng.uniform(-k, k, (4 * H,)).astype(np.float32)
-            sd["fc.weight"] = rng.uniform(-k, k, (D, H)).astype(np.float32)
-            sd["fc.bias"] = rng.uniform(-k, k, (D,)).astype(np.float32)
-            rm.load_state_dict({n: torch.from_numpy(v) for n, v in sd.items()})
+            rm.load_state_dict(seeded_params(C, H, L, D))
             rm = rm.to(device).eval()
-            res["retrieval"] = retrieval_acceptance(rm, filt, device)
+            res["retrieval"] = retrieval_acceptance(rm, filt, device, rtag)
             check_device_status(rm)
             del rm
         if world == 1 and args.dtype == "bf16" and not args.no_f32_line:

@@ -14,7 +14,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CSN_LIB_PATH") or os.path.join(_HERE, "lib", "libcsn_hip.so")
 
 CSN_F32, CSN_BF16 = 0, 1
-ABI_VERSION = 2
+STATUS_TIMEOUT, STATUS_NONFINITE, STATUS_STALE_SLOT = 1, 2, 4      # bits of csn_lstm_status_read (include/csn_hip.h)
+ABI_VERSION = 3
 
 _c_void_p, _c_int, _c_i64, _c_size_t, _c_float = (ctypes.c_void_p, ctypes.c_int, ctypes.c_int64,
                                                   ctypes.c_size_t, ctypes.c_float)
@@ -64,7 +65,8 @@ SIGNATURES = {
                                        _c_void_p, _c_int, _c_int, _c_int, _c_void_p]),
     "csn_lstm_cell_backward": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_i64, _c_void_p, _c_void_p, _c_void_p,
                                         _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p]),
-    "csn_cosine_loss": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_void_p, _c_void_p, _c_float, _c_void_p]),
+    "csn_cosine_loss_scratch_bytes": (_c_size_t, [_c_int]),
+    "csn_cosine_loss": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_void_p, _c_void_p, _c_float, _c_void_p, _c_void_p]),
     "csn_rmsprop_step": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_i64, _c_float, _c_float, _c_float, _c_void_p]),
     "csn_barlow_offdiag_sqsum": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_void_p]),
     "csn_l2_topk_scratch_bytes": (_c_size_t, [_c_i64, _c_i64]),
@@ -140,8 +142,9 @@ def eeg_bandpass_znorm(x_bct, sos, ddof=0, out_dtype=torch.float32, time_major=F
     B, C, T = x.shape
     sos = np.ascontiguousarray(np.asarray(sos, dtype=np.float64).reshape(-1, 6)) if sos is not None else np.zeros((0, 6))
     y = torch.empty((T, B, C) if time_major else (B, T, C), dtype=out_dtype, device=x.device)
-    _check(load().csn_eeg_bandpass_znorm(_ptr(x), B, C, T, sos.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
-                                         sos.shape[0], int(ddof), _ptr(y), _dt(out_dtype), int(time_major), _stream()))
+    with torch.cuda.device(x.device):
+        _check(load().csn_eeg_bandpass_znorm(_ptr(x), B, C, T, sos.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
+                                             sos.shape[0], int(ddof), _ptr(y), _dt(out_dtype), int(time_major), _stream()))
     return y
 
 
@@ -156,8 +159,9 @@ def eeg_filtfilt(x_stc, sos):
     scratch = torch.empty(max(1, lib.csn_eeg_filtfilt_scratch_bytes(S, T, C, sos.shape[0])), dtype=torch.uint8,
                           device=x.device)
     y = torch.empty_like(x)
-    _check(lib.csn_eeg_filtfilt(_ptr(x), S, T, C, sos.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), sos.shape[0],
-                                _ptr(y), _ptr(scratch), _stream()))
+    with torch.cuda.device(x.device):
+        _check(lib.csn_eeg_filtfilt(_ptr(x), S, T, C, sos.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), sos.shape[0],
+                                    _ptr(y), _ptr(scratch), _stream()))
     return y
 
 
@@ -291,8 +295,9 @@ class LstmPlan:
             _check(load().csn_lstm_status_raise(self._plan, self._ws_ptr, _stream()))
 
     def status(self, clear=False):
-        """Blocking: 0 if every in-kernel hand-off since the last clear completed (the word is sticky: a time-out
-        in ANY forward / backward since then keeps it raised)."""
+        """Blocking: 0 if every in-kernel hand-off since the last clear completed; bit STATUS_TIMEOUT = a bounded wait
+        gave up, bit STATUS_NONFINITE = a NaN / Inf gradient reached the backward (the word is sticky: an event in ANY
+        forward / backward since the last clear keeps it raised)."""
         out = _c_int(0)
         _check(load().csn_lstm_status_read(self._plan, self._ws_ptr, ctypes.byref(out)))
         if clear and out.value != 0:
@@ -319,7 +324,10 @@ def cosine_loss(student, teacher, want_grad=True, grad_scale=1.0):
     B, D = s.shape
     loss = torch.empty(1, dtype=torch.float32, device=s.device)
     ds = torch.empty_like(s) if want_grad else None
-    _check(load().csn_cosine_loss(_ptr(s), _ptr(t), B, D, _ptr(loss), _ptr(ds), float(grad_scale), _stream()))
+    lib = load()
+    scratch = torch.empty(lib.csn_cosine_loss_scratch_bytes(B) // 8, dtype=torch.float64, device=s.device)   # caller-owned
+    with torch.cuda.device(s.device):
+        _check(lib.csn_cosine_loss(_ptr(s), _ptr(t), B, D, _ptr(loss), _ptr(ds), float(grad_scale), _ptr(scratch), _stream()))
     return loss, ds
 
 
@@ -329,8 +337,9 @@ def rmsprop_step(params_flat, grads_flat, square_avg_flat, lr, alpha=0.99, eps=1
     n = params_flat.numel()
     assert grads_flat.numel() == n and square_avg_flat.numel() == n
     assert params_flat.dtype == grads_flat.dtype == square_avg_flat.dtype == torch.float32
-    _check(load().csn_rmsprop_step(_ptr(params_flat), _ptr(grads_flat), _ptr(square_avg_flat), n, float(lr), float(alpha),
-                                   float(eps), _stream()))
+    with torch.cuda.device(params_flat.device):
+        _check(load().csn_rmsprop_step(_ptr(params_flat), _ptr(grads_flat), _ptr(square_avg_flat), n, float(lr), float(alpha),
+                                       float(eps), _stream()))
 
 
 def barlow_offdiag_sqsum(c):

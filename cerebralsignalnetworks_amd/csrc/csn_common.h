@@ -48,7 +48,7 @@ int fail(int status, const char* fmt, ...);
 // library keeps no mutable global state, so plans on different streams / threads / devices never share any.
 struct Options {
   bool cell_v1, no_persist, no_persist_bwd, persist_streams, no_xcd_local, no_rotate, no_fuse_x, no_beside,
-      no_side_stream, gemm_slot, fwd_ksplit, fwd_nsplit, fwd_halves, fwd_ws, fwd_flags, bwd_flags, dpoll_no_hint, fwd_hint, beside_fwd, xproj_bf16, wgrad_overlap, gemm_no_dma, gemm_no_256, gemm_generic, gemm_lds64, tn_no_tr, tn_no_stagger, filter_v1;
+      no_side_stream, gemm_slot, fwd_ksplit, fwd_nsplit, fwd_halves, fwd_ws, fwd_flags, bwd_flags, dpoll_no_hint, fwd_hint, beside_fwd, xproj_bf16, wgrad_overlap, gemm_no_dma, gemm_no_256, gemm_generic, gemm_lds64, tn_no_tr, tn_no_stagger, filter_v1, tags_no_rearm;
   int chunk;       // timesteps per weight-stationary launch
   int tn_stages;   // LDS-DMA ring depth of the 256 x 256 weight-gradient kernel
   int fwd_nk;
@@ -72,22 +72,27 @@ static inline Options options_from_env() {
   o.gemm_slot = on("CSN_GEMM_SLOT");
   o.fwd_ksplit = on("CSN_FWD_KSPLIT");
   o.fwd_nsplit = on("CSN_FWD_NSPLIT");
+#ifdef CSN_EXPERIMENTS      // losing variants: only lib/libcsn_hip_experiments.so (`make experiments`) honours these
   o.fwd_halves = on("CSN_FWD_HALVES");
   o.fwd_ws = on("CSN_FWD_WS");
+  o.beside_fwd = on("CSN_BESIDE_FWD");
+  o.xproj_bf16 = on("CSN_XPROJ_BF16");
+  o.wgrad_overlap = on("CSN_WGRAD_OVERLAP");
+#endif
   o.fwd_flags = on("CSN_FWD_FLAGS");
   o.bwd_flags = on("CSN_BWD_FLAGS");
   o.dpoll_no_hint = on("CSN_DPOLL_NO_HINT");
   o.fwd_hint = on("CSN_FWD_HINT");
   o.tn_no_stagger = on("CSN_TN_NO_STAGGER");
-  o.beside_fwd = on("CSN_BESIDE_FWD");
-  o.xproj_bf16 = on("CSN_XPROJ_BF16");
-  o.wgrad_overlap = on("CSN_WGRAD_OVERLAP");
   o.gemm_no_dma = on("CSN_GEMM_NO_DMA");
   o.gemm_no_256 = on("CSN_GEMM_NO_256");
   o.gemm_generic = on("CSN_GEMM_GENERIC");
   o.gemm_lds64 = on("CSN_GEMM_LDS64");
   o.tn_no_tr = on("CSN_TN_NO_TR");
   o.filter_v1 = on("CSN_FILTER_V1");
+#ifdef CSN_SLAB_TAGS
+  o.tags_no_rearm = on("CSN_TAGS_NO_REARM");     // fault injection of the debug library (lstm_cell_blk.h)
+#endif
   o.chunk = num("CSN_LSTM_CHUNK", 32);
   if (o.chunk < 1) o.chunk = 1;
   o.tn_stages = num("CSN_TN_STAGES", 4);

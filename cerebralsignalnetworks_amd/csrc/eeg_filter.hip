@@ -22,7 +22,7 @@ struct SosParams {
 };
 
 template <int NSEC>
-__device__ __forceinline__ double biquad_cascade(double v, const SosParams& p, double (&s1)[8], double (&s2)[8]) {
+__host__ __device__ __forceinline__ double biquad_cascade(double v, const SosParams& p, double (&s1)[8], double (&s2)[8]) {
 #pragma unroll
   for (int s = 0; s < NSEC; ++s) {
     const double y = fma(p.c[s][0], v, s1[s]);
@@ -96,172 +96,218 @@ __global__ void __launch_bounds__(64) eeg_filter_rows_kernel(const float* __rest
 }
 
 // ---------------------------------------------------------------------------------------------
-// v2 kernel ("scan"): the time recurrence is parallelised, so the kernel is HBM-bound instead of
-// bound by one lane walking 500 dependent steps.
-//   A workgroup takes 16 consecutive rows (channels) and cuts each into 16 chunks of 32 samples;
-//   thread (row, chunk) filters its chunk from a ZERO state (float64), giving the zero-state
-//   response and the chunk's end state.  The cascade is linear, so the true output is
-//       y[n] = y_zero_state[n] + sum_i s0_i * phi_i[n],   s0(chunk k+1) = A^32 s0(chunk k) + end_k
-//   with phi_i = response to a unit initial state component and A^32 the 32-step state transition --
-//   both produced once per call by a tiny basis kernel.  Row statistics come from the corrected
-//   chunks; everything stays in LDS between the coalesced load (16 rows are one contiguous 32 KB
-//   run of x) and the transposed, channel-fastest store.
-// LDS: 16 x 546 floats (chunk stride 33, row stride 546 = 2 mod 32: conflict-free for the
-// per-chunk walk AND for the transposed read of the store phase) + end states + statistics.
+// v3 kernel ("scan"): the time recurrence is parallelised and everything between the load and the
+// transposed store lives in registers, so the kernel runs at the speed of its loads and stores.
+//   A workgroup (512 threads) takes 32 consecutive rows (channels); the 16 lanes of a DPP row are the
+//   16 chunks of 32 samples of ONE row.  Thread (row, chunk):
+//     1. loads its 32 samples (8 x 16 B; the four rows of a wave are one contiguous 8 KB run of x),
+//     2. filters them from a ZERO state in float64 (the poles of this band sit at radius 0.9997:
+//        float32 state costs 2e-4) -> zero-state response + the chunk's end state e_k,
+//     3. the cascade is linear, so the true state at the end of chunk k is S_k = A S_{k-1} + e_k with
+//        A the 32-step state transition: a Kogge-Stone scan over the 16 lanes in 4 steps,
+//        S_k += A^(2^m) S_{k-2^m}, the exchange by DPP row shifts (no LDS, no barrier),
+//     4. adds the homogeneous response  y[n] += sum_i S_{k-1,i} phi_i[n]  (phi_i = response to a unit
+//        state component) and accumulates the row statistics (DPP rotations over the 16 lanes),
+//     5. normalises and hands the tile to LDS once, for the channel-fastest store: 16 B per lane,
+//        8 lanes = the 32 channels of one time step = one full 128-byte line.
+//   phi and the four powers of A depend on the coefficients alone: computed on the HOST per call
+//   (192 cascade steps) and passed by value with the kernel arguments -- no device buffer, no setup
+//   launch, nothing shared between calls (the previous version kept a per-device global and re-ran a
+//   setup kernel on the caller's stream every call).
+// LDS: tile[t][32 channels] f32, 64 KB, column of (row r, chunk k) rotated by 4 (k & 7): the 32 lanes
+// of a store group (2 rows x 16 chunks) then hit every bank at most twice (free for ds_write_b32) and a
+// 16-lane group of the 16-byte reads covers all 64 banks once.
 // ---------------------------------------------------------------------------------------------
-static constexpr int kScanRows = 16, kScanChunks = 16, kScanLen = 32, kScanRS = 546;
+static constexpr int kScanRows = 32, kScanChunks = 16, kScanLen = 32;
 
+template <int NSEC>
 struct ScanBasis {
-  double phi[16][kScanLen];   // [state component][n]
-  double apow[16][16];        // [j][i] = component j of the state after kScanLen steps from e_i
+  static constexpr int NS = NSEC > 0 ? 2 * NSEC : 1;
+  double phi[NS][kScanLen];    // [state component][n]
+  double apow[4][NS][NS];      // apow[m][j][i] = component j of the state 32 * 2^m steps after e_i
 };
 
 template <int NSEC>
-__global__ void __launch_bounds__(64) eeg_filter_basis_kernel(SosParams p, ScanBasis* out) {
-  const int i = threadIdx.x;
-  if (i >= 2 * NSEC) return;
-  double s1[8], s2[8];
-#pragma unroll
-  for (int s = 0; s < 8; ++s) { s1[s] = 0.0; s2[s] = 0.0; }
-#pragma unroll
-  for (int s = 0; s < NSEC; ++s) {
-    if (i == 2 * s) s1[s] = 1.0;
-    if (i == 2 * s + 1) s2[s] = 1.0;
+static void fill_scan_basis(const SosParams& p, ScanBasis<NSEC>* b) {
+  constexpr int NS = ScanBasis<NSEC>::NS;
+  for (int i = 0; i < NS; ++i) {
+    double s1[8] = {0.0}, s2[8] = {0.0};
+    for (int s = 0; s < NSEC; ++s) {
+      if (i == 2 * s) s1[s] = 1.0;
+      if (i == 2 * s + 1) s2[s] = 1.0;
+    }
+    for (int n = 0; n < kScanLen; ++n) b->phi[i][n] = NSEC > 0 ? biquad_cascade<NSEC>(0.0, p, s1, s2) : 0.0;
+    for (int j = 0; j < NS; ++j) b->apow[0][j][i] = 0.0;
+    for (int s = 0; s < NSEC; ++s) {
+      b->apow[0][2 * s][i] = s1[s];
+      b->apow[0][2 * s + 1][i] = s2[s];
+    }
   }
-  for (int n = 0; n < kScanLen; ++n) out->phi[i][n] = biquad_cascade<NSEC>(0.0, p, s1, s2);
+  for (int m = 1; m < 4; ++m)
+    for (int j = 0; j < NS; ++j)
+      for (int i = 0; i < NS; ++i) {
+        double a = 0.0;
+        for (int l = 0; l < NS; ++l) a += b->apow[m - 1][j][l] * b->apow[m - 1][l][i];
+        b->apow[m][j][i] = a;
+      }
+}
+
+// lane l of a 16-lane DPP row <- lane l - N (zero where there is none) / lane (l - N) mod 16
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+#define CSN_DPP_ROW_SHR(n) (0x110 | (n))
+#define CSN_DPP_ROW_ROR(n) (0x120 | (n))
+
+template <int NSEC, int M>
+__device__ __forceinline__ void scan_step(double (&sv)[ScanBasis<NSEC>::NS], const ScanBasis<NSEC>& bs) {
+  constexpr int NS = ScanBasis<NSEC>::NS;
+  double sh[NS];
 #pragma unroll
-  for (int s = 0; s < NSEC; ++s) {
-    out->apow[2 * s][i] = s1[s];
-    out->apow[2 * s + 1][i] = s2[s];
-  }
+  for (int i = 0; i < NS; ++i) sh[i] = dpp_f64<CSN_DPP_ROW_SHR(1 << M)>(sv[i]);
+#pragma unroll
+  for (int j = 0; j < NS; ++j)
+#pragma unroll
+    for (int i = 0; i < NS; ++i) sv[j] = fma(bs.apow[M][j][i], sh[i], sv[j]);
+}
+
+__device__ __forceinline__ double row16_sum(double v) {
+  v += dpp_f64<CSN_DPP_ROW_ROR(8)>(v);
+  v += dpp_f64<CSN_DPP_ROW_ROR(4)>(v);
+  v += dpp_f64<CSN_DPP_ROW_ROR(2)>(v);
+  v += dpp_f64<CSN_DPP_ROW_ROR(1)>(v);
+  return v;
+}
+
+template <typename OutT>
+__device__ __forceinline__ void store_quad(OutT* dst, const float4& v);
+template <>
+__device__ __forceinline__ void store_quad<float>(float* dst, const float4& v) { *reinterpret_cast<float4*>(dst) = v; }
+template <>
+__device__ __forceinline__ void store_quad<bf16_t>(bf16_t* dst, const float4& v) {
+  bf16x4 o;
+  o[0] = (bf16_t)v.x; o[1] = (bf16_t)v.y; o[2] = (bf16_t)v.z; o[3] = (bf16_t)v.w;
+  *reinterpret_cast<bf16x4*>(dst) = o;
 }
 
 template <int NSEC, typename OutT>
-__global__ void __launch_bounds__(256)
-eeg_filter_scan_kernel(const float* __restrict__ x, OutT* __restrict__ y, int B, int C, int T, SosParams p,
-                       const ScanBasis* __restrict__ basis, int ddof, int time_major) {
-  constexpr int NS = 2 * NSEC > 0 ? 2 * NSEC : 1;
-  __shared__ float xs[kScanRows * kScanRS];
-  __shared__ double ez[kScanRows][kScanChunks][NS];
-  __shared__ double st[kScanRows][kScanChunks][2];
-  __shared__ double phi_s[NS][kScanLen];
-  __shared__ double apow_s[NS][NS];
+__global__ void __launch_bounds__(512, 4)
+eeg_filter_scan_kernel(const float* __restrict__ x, OutT* __restrict__ y, int B, int C, int T, const SosParams p,
+                       const ScanBasis<NSEC> bs, int ddof, int time_major) {
+  constexpr int NS = ScanBasis<NSEC>::NS;
+  __shared__ __attribute__((aligned(16))) float tile[kScanChunks * kScanLen * kScanRows];     // [t][channel], 64 KB
   const int tid = threadIdx.x;
+  const int k = tid & 15, rl = tid >> 4;
   const int64_t rows_total = (int64_t)B * C;
   const int64_t row0 = (int64_t)blockIdx.x * kScanRows;
-  const int nrows = (int)((rows_total - row0 < kScanRows) ? rows_total - row0 : kScanRows);
+  const int64_t row = row0 + rl;
+  const bool rok = row < rows_total;
+  const int t0 = k * kScanLen;
 
-  // ---- phase 1: coalesced load of nrows x T floats (one contiguous run of x) into the skewed tile
+  // ---- 1: this thread's 32 samples (zeros beyond T / beyond the last row)
+  double v[kScanLen];
   {
-    const float* src = x + row0 * (int64_t)T;
-    const int total = nrows * T;
+    const float* src = x + row * (int64_t)T + t0;
     if ((T & 3) == 0) {
-      for (int e = tid * 4; e < total; e += 256 * 4) {
-        const float4 v = *reinterpret_cast<const float4*>(src + e);
-        const int r = e / T, t = e - r * T;
-        float* d = xs + r * kScanRS + (t >> 5) * 33 + (t & 31);
-        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+#pragma unroll
+      for (int i = 0; i < kScanLen / 4; ++i) {
+        float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (rok && t0 + 4 * i < T) q = *reinterpret_cast<const float4*>(src + 4 * i);
+        v[4 * i + 0] = (double)q.x; v[4 * i + 1] = (double)q.y; v[4 * i + 2] = (double)q.z; v[4 * i + 3] = (double)q.w;
       }
     } else {
-      for (int e = tid; e < total; e += 256) {
-        const int r = e / T, t = e - r * T;
-        xs[r * kScanRS + (t >> 5) * 33 + (t & 31)] = src[e];
+#pragma unroll
+      for (int j = 0; j < kScanLen; ++j) v[j] = (rok && t0 + j < T) ? (double)src[j] : 0.0;
+    }
+  }
+
+  if constexpr (NSEC > 0) {
+    // ---- 2: zero-state response in place, end state
+    double sv[NS];
+    {
+      double s1[8], s2[8];
+#pragma unroll
+      for (int s = 0; s < 8; ++s) { s1[s] = 0.0; s2[s] = 0.0; }
+#pragma unroll
+      for (int j = 0; j < kScanLen; ++j) v[j] = biquad_cascade<NSEC>(v[j], p, s1, s2);
+#pragma unroll
+      for (int s = 0; s < NSEC; ++s) { sv[2 * s] = s1[s]; sv[2 * s + 1] = s2[s]; }
+    }
+    // ---- 3: inclusive scan of the end states over the row's 16 chunks; this chunk starts from S_{k-1}
+    scan_step<NSEC, 0>(sv, bs);
+    scan_step<NSEC, 1>(sv, bs);
+    scan_step<NSEC, 2>(sv, bs);
+    scan_step<NSEC, 3>(sv, bs);
+    double s0[NS];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) s0[i] = dpp_f64<CSN_DPP_ROW_SHR(1)>(sv[i]);
+    // ---- 4a: homogeneous response
+#pragma unroll
+    for (int j = 0; j < kScanLen; ++j)
+#pragma unroll
+      for (int i = 0; i < NS; ++i) v[j] = fma(s0[i], bs.phi[i][j], v[j]);
+  }
+
+  // ---- 4b: row statistics (samples beyond T do not count)
+  double sum = 0.0, sumsq = 0.0;
+#pragma unroll
+  for (int j = 0; j < kScanLen; ++j) {
+    const double m = (t0 + j < T) ? v[j] : 0.0;
+    sum += m;
+    sumsq = fma(m, m, sumsq);
+  }
+  sum = row16_sum(sum);
+  sumsq = row16_sum(sumsq);
+  const double mean = sum / (double)T;
+  const double inv = 1.0 / sqrt((sumsq - sum * mean) / (double)(T - ddof));
+
+  // ---- 5: normalise, transpose through LDS, store channel-fastest
+  {
+    const int col = (rl + 4 * (k & 7)) & 31;
+#pragma unroll
+    for (int j = 0; j < kScanLen; ++j) tile[(t0 + j) * kScanRows + col] = (float)((v[j] - mean) * inv);
+  }
+  __syncthreads();
+  const bool quad_ok = (C & 3) == 0;            // the 4 rows of a quad are 4 consecutive channels of one segment
+#pragma unroll
+  for (int it = 0; it < kScanChunks * kScanLen * 8 / 512; ++it) {
+    const int idx = it * 512 + tid;
+    const int q = idx & 7, t = idx >> 3;
+    if (t >= T) continue;
+    const float4 o = *reinterpret_cast<const float4*>(tile + t * kScanRows + ((4 * q + 4 * ((t >> 5) & 7)) & 31));
+    const int64_t r4 = row0 + 4 * q;
+    if (quad_ok) {
+      if (r4 >= rows_total) continue;
+      const int b = (int)(r4 / C), ch = (int)(r4 % C);
+      OutT* dst = y + (time_major ? ((int64_t)t * B + b) * C + ch : ((int64_t)b * T + t) * C + ch);
+      store_quad<OutT>(dst, o);
+    } else {
+      const float ov[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (r4 + e >= rows_total) continue;
+        const int b = (int)((r4 + e) / C), ch = (int)((r4 + e) % C);
+        y[time_major ? ((int64_t)t * B + b) * C + ch : ((int64_t)b * T + t) * C + ch] = from_f32<OutT>(ov[e]);
       }
     }
-    for (int e = tid; e < NS * kScanLen; e += 256) phi_s[e / kScanLen][e % kScanLen] = basis->phi[e / kScanLen][e % kScanLen];
-    for (int e = tid; e < NS * NS; e += 256) apow_s[e / NS][e % NS] = basis->apow[e / NS][e % NS];
   }
-  __syncthreads();
-
-  // ---- phase 2: zero-state response of chunk k of row r, in place
-  const int r = tid & 15, k = tid >> 4;
-  const int t_beg = k * kScanLen;
-  const int len = (t_beg >= T) ? 0 : ((T - t_beg < kScanLen) ? T - t_beg : kScanLen);
-  float* mine = xs + r * kScanRS + k * 33;
-  {
-    double s1[8], s2[8];
-#pragma unroll
-    for (int s = 0; s < 8; ++s) { s1[s] = 0.0; s2[s] = 0.0; }
-    if (r < nrows)
-      for (int j = 0; j < len; ++j) mine[j] = (float)biquad_cascade<NSEC>((double)mine[j], p, s1, s2);
-#pragma unroll
-    for (int s = 0; s < NSEC; ++s) {
-      ez[r][k][2 * s] = s1[s];
-      ez[r][k][2 * s + 1] = s2[s];
-    }
-  }
-  __syncthreads();
-
-  // ---- phase 3: true initial state of this chunk = fold of the earlier chunks' end states
-  double s0[NS];
-#pragma unroll
-  for (int i = 0; i < NS; ++i) s0[i] = 0.0;
-  for (int kk = 0; kk < k; ++kk) {
-    double nx[NS];
-#pragma unroll
-    for (int j = 0; j < NS; ++j) {
-      double a = ez[r][kk][j];
-#pragma unroll
-      for (int i = 0; i < NS; ++i) a = fma(apow_s[j][i], s0[i], a);
-      nx[j] = a;
-    }
-#pragma unroll
-    for (int j = 0; j < NS; ++j) s0[j] = nx[j];
-  }
-
-  // ---- phase 4: add the homogeneous response, accumulate the row statistics
-  double sum = 0.0, sumsq = 0.0;
-  if (r < nrows)
-    for (int j = 0; j < len; ++j) {
-      double v = (double)mine[j];
-#pragma unroll
-      for (int i = 0; i < (NSEC > 0 ? NS : 0); ++i) v = fma(s0[i], phi_s[i][j], v);
-      sum += v;
-      sumsq = fma(v, v, sumsq);
-      mine[j] = (float)v;
-    }
-  st[r][k][0] = sum;
-  st[r][k][1] = sumsq;
-  __syncthreads();
-
-  // ---- phase 5: normalise and store channel-fastest: lane = (channel c, time phase tq)
-  const int c = tid & 15, tq = tid >> 4;
-  if (c >= nrows) return;
-  double tsum = 0.0, tsq = 0.0;
-#pragma unroll
-  for (int kk = 0; kk < kScanChunks; ++kk) { tsum += st[c][kk][0]; tsq += st[c][kk][1]; }
-  const double mean = tsum / (double)T;
-  const double inv = 1.0 / sqrt((tsq - tsum * mean) / (double)(T - ddof));
-  const float meanf = (float)mean, invf = (float)inv;
-  const int64_t row = row0 + c;
-  const int b = (int)(row / C), ch = (int)(row % C);
-  const int64_t t_stride = time_major ? (int64_t)B * C : (int64_t)C;
-  OutT* yo = y + (time_major ? (int64_t)b * C + ch : ((int64_t)b * T) * C + ch);
-  const float* src = xs + c * kScanRS;
-  for (int t = tq; t < T; t += 16) {
-    const double v = ((double)src[(t >> 5) * 33 + (t & 31)] - mean) * inv;
-    yo[(int64_t)t * t_stride] = from_f32<OutT>((float)v);
-  }
-  (void)meanf; (void)invf;
 }
-
-static ScanBasis* g_basis[16] = {nullptr};
 
 template <int NSEC>
 static int launch_scan(const float* x, void* y, int B, int C, int T, const SosParams& p, int ddof, int out_dtype,
                        int time_major, hipStream_t st) {
-  int dev = 0;
-  CSN_HIP_CHECK(hipGetDevice(&dev));
-  CSN_REQUIRE(dev >= 0 && dev < 16, "device index %d out of range", dev);
-  if (g_basis[dev] == nullptr) CSN_HIP_CHECK(hipMalloc((void**)&g_basis[dev], sizeof(ScanBasis)));
-  eeg_filter_basis_kernel<NSEC><<<1, 64, 0, st>>>(p, g_basis[dev]);
-  CSN_LAUNCH_CHECK();
+  ScanBasis<NSEC> bs;
+  fill_scan_basis<NSEC>(p, &bs);
   const int64_t rows = (int64_t)B * C;
   const unsigned grid = (unsigned)((rows + kScanRows - 1) / kScanRows);
   if (out_dtype == CSN_BF16)
-    eeg_filter_scan_kernel<NSEC, bf16_t><<<grid, 256, 0, st>>>(x, (bf16_t*)y, B, C, T, p, g_basis[dev], ddof, time_major);
+    eeg_filter_scan_kernel<NSEC, bf16_t><<<grid, 512, 0, st>>>(x, (bf16_t*)y, B, C, T, p, bs, ddof, time_major);
   else
-    eeg_filter_scan_kernel<NSEC, float><<<grid, 256, 0, st>>>(x, (float*)y, B, C, T, p, g_basis[dev], ddof, time_major);
+    eeg_filter_scan_kernel<NSEC, float><<<grid, 512, 0, st>>>(x, (float*)y, B, C, T, p, bs, ddof, time_major);
   CSN_LAUNCH_CHECK();
   return CSN_OK;
 }

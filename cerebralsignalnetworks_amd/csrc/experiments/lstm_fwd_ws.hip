@@ -40,10 +40,10 @@
 // fragments in AGPRs + 8 in VGPRs (an MFMA takes its A operand from either), 2 accumulators, 4 operand fragments.
 // Gate waves: 96 AGPRs of W_ih + 24 pre-activations + 16-24 input + 6 c + math.
 // LDS: 4 x 24 KB h buffers + 4 x 8 KB tile slots (reused as the chain's transpose area) + 64 B of counters.
-#include "csn_common.h"
-#include "lstm_cell_common.h"
-#include "lstm_cell_blk.h"
-#include "lstm_ns_util.h"
+#include "../csn_common.h"
+#include "../lstm_cell_common.h"
+#include "../lstm_cell_blk.h"
+#include "../lstm_ns_util.h"
 
 #ifdef CSN_PSTAMPS
 #ifndef CSN_STAMP_BLOCK

@@ -81,27 +81,19 @@ __global__ void __launch_bounds__(1024) barlow_kernel(const float* __restrict__ 
 
 using namespace csn;
 
-// The per-row cosines live in a small device buffer owned by the library (grown on demand,
-// one per process; calls on different streams must not overlap -- the trainer uses one stream).
-static double* g_cos_rows = nullptr;
-static int g_cos_cap = 0;
+// The per-row cosines go through caller-owned scratch: the library keeps no buffer of its own (ABI 3).
+extern "C" size_t csn_cosine_loss_scratch_bytes(int B) { return B > 0 ? (size_t)B * sizeof(double) : 0; }
 
 extern "C" int csn_cosine_loss(const float* student, const float* teacher, int B, int D, float* loss, float* dstudent,
-                               float grad_scale, csnStream_t stream) {
-  CSN_REQUIRE(student && teacher && loss, "csn_cosine_loss: null pointer");
+                               float grad_scale, void* scratch, csnStream_t stream) {
+  CSN_REQUIRE(student && teacher && loss && scratch, "csn_cosine_loss: null pointer");
   CSN_REQUIRE(B > 0 && D > 0, "csn_cosine_loss: bad shape B=%d D=%d", B, D);
+  CSN_REQUIRE((reinterpret_cast<uintptr_t>(scratch) & 7) == 0, "csn_cosine_loss: scratch must be 8-byte aligned");
   hipStream_t st = as_stream(stream);
-  if (B > g_cos_cap) {
-    if (g_cos_rows) CSN_HIP_CHECK(hipFree(g_cos_rows));
-    g_cos_rows = nullptr;
-    g_cos_cap = 0;
-    const int cap = B < 4096 ? 4096 : B;
-    CSN_HIP_CHECK(hipMalloc((void**)&g_cos_rows, (size_t)cap * sizeof(double)));
-    g_cos_cap = cap;
-  }
-  cosine_rows_kernel<<<(unsigned)((B + 3) / 4), 256, 0, st>>>(student, teacher, B, D, g_cos_rows, dstudent, grad_scale);
+  double* cos_rows = (double*)scratch;
+  cosine_rows_kernel<<<(unsigned)((B + 3) / 4), 256, 0, st>>>(student, teacher, B, D, cos_rows, dstudent, grad_scale);
   CSN_LAUNCH_CHECK();
-  cosine_finish_kernel<<<1, 64, 0, st>>>(g_cos_rows, B, loss);
+  cosine_finish_kernel<<<1, 64, 0, st>>>(cos_rows, B, loss);
   CSN_LAUNCH_CHECK();
   return CSN_OK;
 }

@@ -386,9 +386,11 @@ extern "C" int csn_lstm_status_raise(const csnLstmPlan* P, void* workspace, csnS
 }
 extern "C" int csn_lstm_status_read(const csnLstmPlan* P, const void* workspace, int* status) {
   CSN_REQUIRE(P && workspace && status, "csn_lstm_status_read: null pointer");
-  unsigned flag = 0;
-  CSN_HIP_CHECK(hipMemcpy(&flag, (const char*)workspace + P->w.status, sizeof(flag), hipMemcpyDeviceToHost));
-  *status = (int)flag;
+  // word 0: a bounded wait timed out; word 1: a non-finite gradient reached the backward; word 2 (debug library built
+  // with -DCSN_SLAB_TAGS only): a consumer was served a stale occupant of a hand-off ring slot
+  unsigned flag[3] = {0u, 0u, 0u};
+  CSN_HIP_CHECK(hipMemcpy(flag, (const char*)workspace + P->w.status, sizeof(flag), hipMemcpyDeviceToHost));
+  *status = (flag[0] ? CSN_STATUS_TIMEOUT : 0) | (flag[1] ? CSN_STATUS_NONFINITE : 0) | (flag[2] ? CSN_STATUS_STALE_SLOT : 0);
   return CSN_OK;
 }
 
@@ -671,6 +673,9 @@ static int forward_persist(Plan& P, char* ws, int training, hipStream_t st, Side
   // (forward: no hint words by default -- the first k-block's own pieces are what the wave spins on; measured 205 -> 200 us
   // per launch; CSN_FWD_HINT restores them)
   a.data_polls = (!w.fwd_ns && !P.opt.fwd_flags) ? (P.opt.fwd_hint && !P.opt.dpoll_no_hint ? 1 : 2) : 0;
+#ifdef CSN_SLAB_TAGS
+  if (a.data_polls && P.opt.tags_no_rearm) a.data_polls |= 4;
+#endif
   if (a.data_polls)        // the ring of 4 hand-off slabs of every layer starts as sentinel (lstm_fwd_persist.hip)
     for (int l = 0; l < NL; ++l)
       CSN_HIP_CHECK(hipMemsetAsync(ws + w.layer[l].h_blk_all, 0xff, (size_t)4 * Bpad * H * 2, st));
@@ -681,7 +686,9 @@ static int forward_persist(Plan& P, char* ws, int training, hipStream_t st, Side
   const int max_slots = NL < nch ? NL : nch;
   const int fwd_slices = w.fwd_ns ? fwd_ns_slices(H) : fwd_persist_slices(H);
   auto launch_fwd = [&](const PersistFwdArgs& args, hipStream_t on) {
+#ifdef CSN_EXPERIMENTS
     if (args.chains == 4) return launch_fwd_ws(args, on);
+#endif
     return w.fwd_ns ? launch_fwd_ns(args, on) : launch_fwd_persist(args, on);
   };
   const bool grouped = max_slots <= 4 && max_slots * MT <= 8 && fwd_slices <= 32 &&
@@ -999,6 +1006,9 @@ static int backward_persist(Plan& P, char* ws, const float* dy_last,
   a.grid_slices = 32;
   a.rotate = !P.opt.no_rotate;
   a.data_polls = P.opt.bwd_flags ? 0 : (P.opt.dpoll_no_hint ? 2 : 1);
+#ifdef CSN_SLAB_TAGS
+  if (a.data_polls && P.opt.tags_no_rearm) a.data_polls |= 4;
+#endif
   if (a.data_polls)        // the ring of 4 hand-off slabs of every layer starts as sentinel (lstm_bwd_persist.hip)
     for (int l = 0; l < NL; ++l)
       CSN_HIP_CHECK(hipMemsetAsync(ws + w.layer[l].dg_blk_all, 0xff, (size_t)4 * Bpad * G * 2, st));

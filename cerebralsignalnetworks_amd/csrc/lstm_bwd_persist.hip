@@ -260,7 +260,7 @@ __global__ void __launch_bounds__(256) lstm_bwd_persist_kernel(PersistBwdArgs a)
         const unsigned not_yet = dpoll ? 0xffffffffu : 0u;
         const unsigned long long t_begin = wall_clock64();
         // (data_polls == 2, a test switch: no hint, load straight away -- every step then goes through the re-read path)
-        while (!(dpoll && a.data_polls == 2) && !__all(__hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != not_yet)) {
+        while (!(dpoll && CSN_DPOLL_MODE(a.data_polls) == 2) && !__all(__hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != not_yet)) {
           __builtin_amdgcn_s_sleep(1);
           if (__hip_atomic_load(a.error_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
           if (wall_clock64() - t_begin > kBwdSpinTimeoutTicks) {
@@ -285,6 +285,8 @@ __global__ void __launch_bounds__(256) lstm_bwd_persist_kernel(PersistBwdArgs a)
       // the watched words were ahead of their neighbours, the whole phase is redone.
       const unsigned long long t_phase = wall_clock64();
       bool again = false;
+      int redone = 0;          // data polls: phases redone in this step; from the second on the operand is inspected
+      bool proven = false;     // every piece of the operand was seen to be data (no sentinel left)
       do {
         if (again) {
           __builtin_amdgcn_s_sleep(1);
@@ -307,8 +309,21 @@ __global__ void __launch_bounds__(256) lstm_bwd_persist_kernel(PersistBwdArgs a)
           issue_group(kb);
           __builtin_amdgcn_sched_barrier(0);
         }
+#ifdef CSN_SLAB_TAGS
+        bool stale = false;       // (debug library, see lstm_fwd_persist.hip: a non-sentinel piece with the wrong step tag)
+#endif
 #pragma unroll
         for (int kb = 0; kb < KS; ++kb) {
+#ifdef CSN_SLAB_TAGS
+          if constexpr (dpoll) {
+            const unsigned want = (unsigned)(((t + 1) >> 2) & 1);
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+              const u32x4 u = __builtin_bit_cast(u32x4, df[kb % RING][rg]);
+              stale |= u[0] != 0xffffffffu && (u[0] & 1u) != want;
+            }
+          }
+#endif
 #pragma unroll
           for (int rg = 0; rg < 4; ++rg)
 #pragma unroll
@@ -320,6 +335,9 @@ __global__ void __launch_bounds__(256) lstm_bwd_persist_kernel(PersistBwdArgs a)
             __builtin_amdgcn_sched_barrier(0);
           }
         }
+#ifdef CSN_SLAB_TAGS
+        if (__any(stale) && lane == 0) __hip_atomic_store(a.error_flag + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
         again = false;
         if constexpr (dpoll) {
           // the sentinel is a pair of bf16 NaNs: a piece that was still the sentinel when it was multiplied has
@@ -333,10 +351,33 @@ __global__ void __launch_bounds__(256) lstm_bwd_persist_kernel(PersistBwdArgs a)
 #ifdef CSN_PSTAMPS
             if (lane == 0) atomicAdd(&g_bstamps[8 + wave], 1ull);        // (diagnostic: phases redone, per wave, all workgroups)
 #endif
-            again = __hip_atomic_load(a.error_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u;
-            if (wall_clock64() - t_phase > kBwdSpinTimeoutTicks) {
-              __hip_atomic_store(a.error_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              again = false;
+            if (proven) {
+              // the operand was all data and the product is still not finite: a genuine non-finite gradient (NaN / Inf
+              // input, Inf - Inf in the accumulators).  The reference propagates it; so do we -- no spin, and a status
+              // bit of its own (word 1) so that the host can tell it from a hand-off that timed out (word 0)
+              if (lane == 0) __hip_atomic_store(a.error_flag + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+              if (++redone >= 2) {
+                // cold path: re-read every piece this wave multiplies and look for the sentinel by bit pattern (a piece
+                // is ONE 16-byte producer store; data NaNs are canonical 0x7fc0 / 0xffc0 patterns, never all ones)
+                bool sentinel = false;
+                int kbo2 = rot_t * 1024;
+#pragma unroll 1
+                for (int kb = 0; kb < KS; ++kb) {
+#pragma unroll
+                  for (int rg = 0; rg < 4; ++rg) {
+                    const u32x4 u = __builtin_bit_cast(u32x4, bload_sc1_b128(slabs_rsrc, base + (unsigned)(rg * kblocks) * 1024u, src_off + kbo2));
+                    sentinel |= (u[0] == 0xffffffffu) | (u[3] == 0xffffffffu);
+                  }
+                  kbo2 = kbo2 + 1024 == KS * 1024 ? 0 : kbo2 + 1024;
+                }
+                proven = !__any(sentinel);     // a written piece stays written until this workgroup publishes dgates_t
+              }
+              again = __hip_atomic_load(a.error_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u;
+              if (wall_clock64() - t_phase > kBwdSpinTimeoutTicks) {
+                __hip_atomic_store(a.error_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                again = false;
+              }
             }
           }
         }
@@ -359,7 +400,7 @@ __global__ void __launch_bounds__(256) lstm_bwd_persist_kernel(PersistBwdArgs a)
     // data polls: re-arm slot (t - 2) & 3 (it holds dgates_{t+2}: every producer has published dgates_{t+1}, so all of
     // them have read it; it is looked at again at step t-3, after this workgroup's dgates_{t-1} was consumed, which
     // is stored behind loads that retire these stores -- the argument of lstm_fwd_persist.hip, mirrored in time)
-    if (dpoll) {
+    if (dpoll && !CSN_DPOLL_NO_REARM(a.data_polls)) {
       const int arm_off = __builtin_amdgcn_readfirstlane(((t + 2) & 3) * slab_bytes);
       const bf16x8 sent = __builtin_bit_cast(bf16x8, (u32x4){0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu});
 #pragma unroll
@@ -384,7 +425,12 @@ __global__ void __launch_bounds__(256) lstm_bwd_persist_kernel(PersistBwdArgs a)
     for (int ps = 0; ps < NPASS; ++ps) {
       if (!pok[ps]) {
         if (dpoll) {        // padding rows of the last M-tile: zeros instead of the sentinel (they feed only their own outputs)
-          const bf16x8 z = __builtin_bit_cast(bf16x8, (u32x4){0u, 0u, 0u, 0u});
+#ifdef CSN_SLAB_TAGS
+          const unsigned ztag = (unsigned)((t >> 2) & 1);
+#else
+          const unsigned ztag = 0u;
+#endif
+          const bf16x8 z = __builtin_bit_cast(bf16x8, (u32x4){ztag, 0u, 0u, 0u});
           const unsigned z0 = (unsigned)(blk_offset(prow[ps], 4 * (int64_t)puq[ps], K) * 2);
           const unsigned z1 = (unsigned)(blk_offset(prow[ps], 4 * (int64_t)puq[ps] + 8, K) * 2);
           if (local) {
@@ -430,6 +476,15 @@ __global__ void __launch_bounds__(256) lstm_bwd_persist_kernel(PersistBwdArgs a)
       // the hand-off payload first: plain stores stay in this XCD's L2 (L2-local groups), write-through otherwise
       const unsigned o0 = (unsigned)(blk_offset(row, 4 * (int64_t)uq, K) * 2);
       const unsigned o1 = (unsigned)(blk_offset(row, 4 * (int64_t)uq + 8, K) * 2);
+#ifdef CSN_SLAB_TAGS      // each 16-byte hand-off piece carries bit 2 of its step in the lowest mantissa bit of its first element
+      {
+        u32x4 ul = __builtin_bit_cast(u32x4, lo), uh = __builtin_bit_cast(u32x4, hi);
+        ul[0] = (ul[0] & ~1u) | (unsigned)((t >> 2) & 1);
+        uh[0] = (uh[0] & ~1u) | (unsigned)((t >> 2) & 1);
+        lo = __builtin_bit_cast(bf16x8, ul);
+        hi = __builtin_bit_cast(bf16x8, uh);
+      }
+#endif
       if (local) {
         bstore_b128<false>(slabs_rsrc, o0, lo, dst_off);
         bstore_b128<false>(slabs_rsrc, o1, hi, dst_off);

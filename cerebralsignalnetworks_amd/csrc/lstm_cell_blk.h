@@ -2,6 +2,16 @@
 #pragma once
 #include "csn_common.h"
 
+// Debug library (-DCSN_SLAB_TAGS, `make tags`): bit 2 of data_polls = fault injection "do not re-arm the ring slots", so
+// that consumers ARE served stale occupants and the tag check can be seen to fire.  The product build has neither.
+#ifdef CSN_SLAB_TAGS
+#define CSN_DPOLL_MODE(x) ((x) & 3)
+#define CSN_DPOLL_NO_REARM(x) (((x) & 4) != 0)
+#else
+#define CSN_DPOLL_MODE(x) (x)
+#define CSN_DPOLL_NO_REARM(x) false
+#endif
+
 namespace csn {
 
 struct CellFwdProb {

@@ -79,14 +79,26 @@ __device__ __forceinline__ bf16x8 load_sc1_b128(__amdgpu_buffer_rsrc_t rsrc, int
   return cvt.b;
 }
 
-__device__ __forceinline__ void store_wt_b64(bf16_t* p, const float (&v)[4]) {
+// CSN_SLAB_TAGS (`make tags`, a DEBUG library): every 8-byte hand-off piece carries, in the lowest mantissa bit of
+// its first element, bit 2 of the step it belongs to.  The previous occupant of a ring slot is the piece of step
+// t - 4, whose tag is the opposite one -- so a consumer that is served a STALE occupant (data, not the sentinel: the
+// one case the sentinel proof cannot see) raises status word 2.  The tag perturbs h by one bf16 ulp: a detection
+// build, not a parity build.
+__device__ __forceinline__ unsigned long long pack_h_piece(const float (&v)[4], int tag) {
   union { bf16x4 b; unsigned long long u; } cvt;
   cvt.b = (bf16x4){(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
-  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), cvt.u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef CSN_SLAB_TAGS
+  cvt.u = (cvt.u & ~1ull) | (unsigned long long)(tag & 1);
+#endif
+  return cvt.u;
 }
 
-__device__ __forceinline__ void store_plain_b64(bf16_t* p, const float (&v)[4]) {
-  *reinterpret_cast<bf16x4*>(p) = (bf16x4){(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+__device__ __forceinline__ void store_wt_b64(bf16_t* p, const float (&v)[4], int tag) {
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), pack_h_piece(v, tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ void store_plain_b64(bf16_t* p, const float (&v)[4], int tag) {
+  *reinterpret_cast<unsigned long long*>(p) = pack_h_piece(v, tag);
 }
 
 // Bounded wait of one lane until *p (read with relaxed agent-scope = sc1 loads, which bypass this CU's L1)
@@ -311,7 +323,7 @@ __global__ void __launch_bounds__(256) lstm_fwd_persist_kernel(PersistFwdArgs a)
         const unsigned not_yet = dpoll ? 0xffffffffu : 0u;
         const unsigned long long t_begin = wall_clock64();
         // (data_polls == 2, a test switch: no hint, load straight away -- every step then goes through the re-read path)
-        while (!(dpoll && a.data_polls == 2) && !__all(__hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != not_yet)) {
+        while (!(dpoll && CSN_DPOLL_MODE(a.data_polls) == 2) && !__all(__hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != not_yet)) {
           __builtin_amdgcn_s_sleep(1);
           if (__hip_atomic_load(a.error_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
           if (wall_clock64() - t_begin > kSpinTimeoutTicks) {
@@ -368,6 +380,18 @@ __global__ void __launch_bounds__(256) lstm_fwd_persist_kernel(PersistFwdArgs a)
             } while (!whole() && __hip_atomic_load(a.error_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u);
           }
         }
+#ifdef CSN_SLAB_TAGS
+        if (dpoll) {        // h_{t-1} was tagged with bit 2 of t - 1; anything else in a non-sentinel piece is a stale occupant
+          const unsigned want = (unsigned)(((t - 1) >> 2) & 1);
+          bool stale = false;
+#pragma unroll
+          for (int rg = 0; rg < 4; ++rg) {
+            const u32x4 u = __builtin_bit_cast(u32x4, hf[ks % RING][rg]);
+            stale |= (u[0] != 0xffffffffu && (u[0] & 1u) != want) | (u[2] != 0xffffffffu && (u[2] & 1u) != want);
+          }
+          if (__any(stale) && lane == 0) __hip_atomic_store(a.error_flag + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+#endif
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg)
 #pragma unroll
@@ -414,7 +438,7 @@ __global__ void __launch_bounds__(256) lstm_fwd_persist_kernel(PersistFwdArgs a)
     //     (A ring of 3 -- re-arming the slot of h_{t+1} -- would leave only issue order between the sentinel and the
     //     h_t the consumer has to see first.)
     //   never over data: h_{t+2} is stored two steps from now, by this same wave.
-    if (dpoll) {
+    if (dpoll && !CSN_DPOLL_NO_REARM(a.data_polls)) {
 #pragma unroll
       for (int ps = 0; ps < NPASS; ++ps) {
         if (tid + ps * 256 >= NPAIR) continue;      // (rows beyond B are padding rows of the slab: re-armed like the rest)
@@ -434,8 +458,13 @@ __global__ void __launch_bounds__(256) lstm_fwd_persist_kernel(PersistFwdArgs a)
         // the sentinel (zeros: the rows feed only their own, never stored, outputs)
         if (dpoll && tid + ps * 256 < NPAIR) {
           unsigned long long* zp = reinterpret_cast<unsigned long long*>(h_blk_all + slot_out * slab + blk_offset(prow[ps], puq[ps], H));
-          if (local) *zp = 0ull;
-          else __hip_atomic_store(zp, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef CSN_SLAB_TAGS
+          const unsigned long long zv = (unsigned long long)((t >> 2) & 1);
+#else
+          const unsigned long long zv = 0ull;
+#endif
+          if (local) *zp = zv;
+          else __hip_atomic_store(zp, zv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         continue;
       }
@@ -462,8 +491,8 @@ __global__ void __launch_bounds__(256) lstm_fwd_persist_kernel(PersistFwdArgs a)
       cst[ps] = make_float4(cn[0], cn[1], cn[2], cn[3]);
       // the hand-off payload first: plain stores stay in this XCD's L2 (L2-local groups), write-through otherwise
       bf16_t* hdst = h_blk_all + slot_out * slab + blk_offset(row, uq, H);
-      if (local) store_plain_b64(hdst, hn);
-      else store_wt_b64(hdst, hn);
+      if (local) store_plain_b64(hdst, hn, t >> 2);
+      else store_wt_b64(hdst, hn, t >> 2);
       if (gates != nullptr) {
         bf16x8 lo = {(bf16_t)gi[0], (bf16_t)gf[0], (bf16_t)gg[0], (bf16_t)go[0], (bf16_t)gi[1], (bf16_t)gf[1], (bf16_t)gg[1], (bf16_t)go[1]};
         bf16x8 hi = {(bf16_t)gi[2], (bf16_t)gf[2], (bf16_t)gg[2], (bf16_t)go[2], (bf16_t)gi[3], (bf16_t)gf[3], (bf16_t)gg[3], (bf16_t)go[3]};

@@ -38,6 +38,7 @@ class FlatGrads:
         total = sum(p.numel() for p in self.params)
         self.flat = torch.zeros(total, dtype=torch.float32, device=self.params[0].device)
         self.flat_params = torch.empty_like(self.flat) if flatten_params else None
+        self.timing = None      # a list -> all_reduce_mean() records an event pair per call
         off = 0
         for p in self.params:
             n = p.numel()
@@ -53,8 +54,22 @@ class FlatGrads:
     def all_reduce_mean(self):
         rank, world = dist_info()
         if world > 1:
+            ev = None
+            if self.timing is not None and self.flat.is_cuda:     # bench.py: event pair on the launching stream
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record()
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
             self.flat.div_(world)
+            if ev is not None:
+                ev[1].record()
+                self.timing.append(ev)
+
+    def all_reduce_ms(self):
+        """Mean milliseconds of the recorded gradient all-reduces (incl. the 1/world scaling); blocking."""
+        if not self.timing:
+            return None
+        torch.cuda.synchronize()
+        return sum(a.elapsed_time(b) for a, b in self.timing) / len(self.timing)
 
 
 class FlatRMSprop:
@@ -68,9 +83,22 @@ class FlatRMSprop:
         self.square_avg = torch.zeros_like(flat.flat)
         self.param_groups = [{"lr": lr, "params": flat.params}]
 
+    def check_views(self):
+        """The parameters must still BE the views into the flat buffer this optimiser steps (model.float() / .to(dtype)
+        / load_state_dict(assign=True) after construction re-home them and the model would silently stop training)."""
+        base, off = self.flat.flat_params.data_ptr(), 0
+        for p in self.flat.params:
+            if p.data_ptr() != base + 4 * off:
+                raise RuntimeError("FlatRMSprop: a parameter no longer lives in the flat buffer (re-homed after the "
+                                   "trainer was built); rebuild the trainer")
+            off += p.numel()
+
     @torch.no_grad()
     def step(self):
         from . import cabi
+        self._steps = getattr(self, "_steps", 0) + 1
+        if self._steps == 1 or self._steps % 256 == 0:
+            self.check_views()
         cabi.rmsprop_step(self.flat.flat_params, self.flat.flat, self.square_avg, self.param_groups[0]["lr"], self.alpha, self.eps)
 
     def zero_grad(self, set_to_none=False):
@@ -111,19 +139,36 @@ def shard_indices(n, epoch, seed, rank, world, shuffle=True, device="cpu"):
 
 
 def check_device_status(model):
-    """Blocking: raises if an in-kernel hand-off of a weight-stationary LSTM kernel timed out in ANY forward /
-    backward of ``model`` since the last check (the status word is sticky; results from that step on are invalid).
-    Call it at epoch ends / after a timed region / after an evaluation pass, not per step.  Cleared once reported."""
+    """Blocking: raises if an in-kernel hand-off of a weight-stationary LSTM kernel timed out, or a non-finite gradient
+    reached the backward recurrence, in ANY forward / backward of ``model`` since the last check (the status word is
+    sticky).  Call it at epoch ends / after a timed region / after an evaluation pass, not per step.  Cleared once
+    reported.  With torch.distributed initialised the verdict is all-reduced (MAX) first, so every rank raises together
+    instead of one rank leaving the others in the next collective."""
+    from . import cabi
     from .lstm_model import HipLSTM
     torch.cuda.synchronize()
-    bad = False
+    bad = 0
+    dev = None
     for mod in model.modules():
         if isinstance(mod, HipLSTM):
             for plan in mod.all_plans():
-                bad |= plan.status(clear=True) != 0
-    if bad:
+                bad |= plan.status(clear=True)
+                dev = plan.device
+    _, world = dist_info()
+    if world > 1:
+        on_gpu = dist.get_backend() == "nccl"
+        t = torch.tensor([bad & 1, (bad >> 1) & 1, (bad >> 2) & 1], dtype=torch.int32,
+                         device=(dev if dev is not None else torch.device("cuda", torch.cuda.current_device())) if on_gpu else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        bad = int(t[0].item()) | (int(t[1].item()) << 1) | (int(t[2].item()) << 2)
+    if bad & cabi.STATUS_TIMEOUT:
         raise RuntimeError("libcsn_hip: a bounded in-kernel wait of the LSTM recurrence timed out "
                            "(is another process using this GPU's CUs?); results are invalid")
+    if bad & cabi.STATUS_STALE_SLOT:      # only the debug library (make tags) can raise this
+        raise RuntimeError("libcsn_hip (tags build): a hand-off ring slot served its previous occupant; results are invalid")
+    if bad & cabi.STATUS_NONFINITE:
+        raise FloatingPointError("libcsn_hip: a non-finite (NaN / Inf) gradient reached the LSTM backward: the run has "
+                                 "diverged (the reference would carry the NaN through its loss and weights)")
 
 
 class DistillTrainer:

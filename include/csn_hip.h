@@ -36,7 +36,7 @@ enum csnStatus {
 enum csnDtype { CSN_F32 = 0, CSN_BF16 = 1 };
 
 /* ABI version of this header; bumped on any signature change. */
-#define CSN_ABI_VERSION 2
+#define CSN_ABI_VERSION 3
 int csn_abi_version(void);
 /* Thread-local message for the last non-zero status returned on this thread. */
 const char* csn_last_error(void);
@@ -53,7 +53,9 @@ const char* csn_target_arch(void);
  *   sos    [host] [nsec,6] float64 rows (b0,b1,b2,a0,a1,a2), nsec <= 8; nsec == 0 = no filter
  *   ddof   0 (numpy path, PerilsEEGDataset.py:555-562) or 1 (torch path, :576-579)
  *   y      out_dtype, laid out [B,T,C] (time_major=0) or [T,B,C] (time_major=1)
- * IIR state and statistics are carried in float64.
+ * IIR state and statistics are carried in float64.  Stateless: what depends on the coefficients alone (the
+ * chunk-scan basis) is computed on the host per call and travels with the kernel arguments -- no device buffer is
+ * kept between calls, so calls with different coefficients on different streams / threads / devices are independent.
  * ---------------------------------------------------------------------------------- */
 int csn_eeg_bandpass_znorm(const float* x, int B, int C, int T,
                            const double* sos, int nsec, int ddof,
@@ -130,13 +132,18 @@ int csn_lstm_backward(csnLstmPlan* plan,
                       float* const* db_ih, float* const* db_hh,
                       float* dx, csnStream_t stream);
 
-/* The workspace's status word: 0 = ok; non-zero = a bounded in-kernel wait of a weight-stationary kernel gave
- * up at some point since the word was last cleared (the results of that forward / backward and of every later
- * one are invalid).  It is STICKY: no forward or backward clears it.  csn_lstm_status_clear zeroes it (enqueued on
+/* The workspace's status word: 0 = ok.  Bit CSN_STATUS_TIMEOUT: a bounded in-kernel wait of a weight-stationary
+ * kernel gave up at some point since the word was last cleared (the results of that forward / backward and of every
+ * later one are invalid).  Bit CSN_STATUS_NONFINITE: a NaN / Inf gradient reached the backward recurrence (the
+ * operand was proven to be data, its product was not finite): the gradients are non-finite exactly as the reference's
+ * autograd would leave them -- a diverged run, not a device fault.  It is STICKY: no forward or backward clears it.  csn_lstm_status_clear zeroes it (enqueued on
  * `stream`): call it once after allocating a workspace and after a reported error has been handled.
  * csn_lstm_status_read is a blocking device -> host read.  csn_lstm_status_raise is fault injection for tests of
  * the error path: it leaves the word exactly as a timed-out wait does (every later bounded wait then returns at
  * once, so nothing hangs; results are garbage by construction). */
+#define CSN_STATUS_TIMEOUT 1
+#define CSN_STATUS_NONFINITE 2
+#define CSN_STATUS_STALE_SLOT 4   /* debug library (make tags) only: a hand-off ring slot served its previous occupant */
 int csn_lstm_status_clear(const csnLstmPlan* plan, void* workspace, csnStream_t stream);
 int csn_lstm_status_read(const csnLstmPlan* plan, const void* workspace, int* status);
 int csn_lstm_status_raise(const csnLstmPlan* plan, void* workspace, csnStream_t stream);
@@ -182,9 +189,12 @@ int csn_lstm_cell_backward(const void* dgates_next, const void* w_hh_t,
  * K5  1 - mean_b cos(student_b, teacher_b), dim=1, eps=1e-8, and its gradient.
  * Replaces: CosineSimilarityLoss.forward, LstmDistillFromDinoV2Train.py:36-43.
  *   loss: [1] float32; dstudent: optional [B,D] float32 = grad_scale * dloss/dstudent.
+ *   scratch: csn_cosine_loss_scratch_bytes(B) bytes of device memory owned by the caller (the per-row cosines; 8-byte
+ *   aligned) -- like csn_l2_topk's: the library holds no buffer of its own between calls.
  * ---------------------------------------------------------------------------------- */
+size_t csn_cosine_loss_scratch_bytes(int B);
 int csn_cosine_loss(const float* student, const float* teacher, int B, int D,
-                    float* loss, float* dstudent, float grad_scale, csnStream_t stream);
+                    float* loss, float* dstudent, float grad_scale, void* scratch, csnStream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Optimiser step of the hot loop over ONE flat float32 parameter / gradient / state buffer (16-byte aligned).

@@ -1,6 +1,6 @@
 """Reference-pinned fixtures: made by EXECUTING the reference's own hot-path definitions (run once, here).
 
-    python tests/golden/make_ref_goldens.py [small|cfg2|cfg4|retrieval|all]
+    python tests/golden/make_ref_goldens.py [small|cfg2|cfg4|retrieval|retrieval_cfg4|all]
 
 ``ref_lift.lift`` compiles the named class / function nodes straight out of the files under /root/reference
 (which cannot be imported as modules: faiss / torchvision / cv2 / librosa / ``models.lstm`` are absent) and
@@ -485,19 +485,20 @@ def ref_dino_step():
 # ------------------------------------------------------------------------------------------------
 # retrieval acceptance set (north star: bf16 top-1 within +-0.5 % of the CPU reference)
 # ------------------------------------------------------------------------------------------------
-def ref_retrieval(n_gallery=2048, n_query=512):
+def ref_retrieval(n_gallery=2048, n_query=512, tag="cfg2", T=500, H=768, seed=101):
     """The reference CPU path (scipy sosfilt + z-score -> the reference's LSTMModel, torch f32, eval) embeds a seeded
-    clustered set at cfg2; stored: its top-5 neighbour lists / top-1 (exact L2 in f64), labels, a sample of the
+    clustered set at cfg2 (128 x 500, hidden 768) or cfg4 (the Spampinato shapes of BASELINE.json configs[3]: 128 x 440,
+    hidden 1024, LstmDistillFromDinoV2TrainSpampinato.py:368; smaller set: the CPU run is the cost); stored: its top-5 neighbour lists / top-1 (exact L2 in f64), labels, a sample of the
     embeddings.  Inputs are regenerated from the seed at test time (cerebralsignalnetworks_amd.dataset.clustered_eeg)."""
     from oracle.lstm import init_params
     from oracle import cpu_path, eeg_filter, retrieval
     from cerebralsignalnetworks_amd.dataset import clustered_eeg
-    C, T, H, L, D = 128, 500, 768, 2, 384
+    C, L, D = 128, 2, 384
     ns = lift("LSTMDistillRetreival.py", ["LSTMModel"])
     params = init_params(C, H, L, D, None, seed=43)
     m = _load_into(ns["LSTMModel"](C, H, L, D), params, torch.float32).eval()
     n = n_gallery + n_query
-    x, labels = clustered_eeg(n)
+    x, labels = clustered_eeg(n, T=T, seed=seed)
     sos = eeg_filter.design_bandpass_sos(1000, 3)
     torch.set_num_threads(8)
     embs = []
@@ -511,7 +512,8 @@ def ref_retrieval(n_gallery=2048, n_query=512):
     Dm, I = retrieval.l2_topk(emb[:n_gallery], emb[n_gallery:], 5)
     top1 = float((labels[:n_gallery][I[:, 0]] == labels[n_gallery:]).mean())
     print("  reference top-1:", top1)
-    _save("ref_retrieval_cfg2.npz", dict(n_gallery=np.array(n_gallery), n_query=np.array(n_query), seed=np.array(101),
+    _save(f"ref_retrieval_{tag}.npz", dict(n_gallery=np.array(n_gallery), n_query=np.array(n_query), seed=np.array(seed),
+                                         dims=np.array([C, T, H, L, D]),
                                          snr=np.array(0.2), labels=labels.astype(np.int16), top5=I.astype(np.int32),
                                          top5_dist=Dm, top1=np.array(top1), emb_sample=emb[::16].astype(np.float32)))
 
@@ -533,3 +535,5 @@ if __name__ == "__main__":
         ref_lstm_full("cfg4", 8, 440, 128, 1024, 2, 384, seed_x=32)
     if what in ("retrieval", "all"):
         ref_retrieval()
+    if what in ("retrieval_cfg4", "all"):
+        ref_retrieval(n_gallery=1536, n_query=384, tag="cfg4", T=440, H=1024, seed=104)

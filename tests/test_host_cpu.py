@@ -331,3 +331,35 @@ def test_spampinato_split_subject_filter_and_dataset_level_norm(tmp_path):
     want = ((items[8]["eeg"] - means) / stds).t()[5:35]                     # (eeg - means) / stddevs at load, :104-105
     np.testing.assert_allclose(ds[0][0].numpy(), want.numpy(), atol=1e-6)
     assert ds[0][1]["ClassId"] == 0 and ds.getLabelbyIndex(1)["ClassId"] == 1
+
+
+def test_bench_launcher_argv_env_and_rank_count_refusals():
+    """`bench.py --gpus N`: the parent builds a torch.distributed.run job of N fresh rank processes (it never touches
+    the GPU itself), a rank whose WORLD_SIZE disagrees with --gpus exits non-zero, and a host with fewer GPUs than
+    asked for is refused instead of silently benching one device (reference launch pattern:
+    EEG-BarlowNetworks/train.py:71,76-78 -- one worker per GPU over a loopback tcp rendezvous)."""
+    import subprocess
+    sys.path.insert(0, ROOT)
+    import bench
+    argv = ["--gpus", "4", "--steps", "7", "--warmup", "2"]
+    cmd, env = bench.launcher_command(4, argv, port=29876)
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29876"
+    i = cmd.index(os.path.join(ROOT, "bench.py"))
+    assert cmd[i + 1:] == argv                       # the ranks get the caller's flags verbatim (incl. --gpus 4)
+    assert env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and "WORLD_SIZE" not in env and "RANK" not in env
+    assert bench.parse(argv).gpus == 4
+    # no GPU in this container: asking for 2 must fail loudly, not print an n_gpus=1 line
+    clean = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "CSN_SINGLE_DEVICE")}
+    if torch.cuda.device_count() < 2:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=clean,
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode != 0 and r.stdout.strip() == "" and "refusing" in r.stderr
+    # a rank launched with the wrong world size exits before touching any device
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=dict(clean, WORLD_SIZE="3", RANK="0"),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and r.stdout.strip() == "" and "WORLD_SIZE=3" in r.stderr
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"], env=dict(clean, WORLD_SIZE="2", RANK="0"),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and r.stdout.strip() == ""

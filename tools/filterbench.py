@@ -19,4 +19,14 @@ for out_dtype, osz in ((torch.float32, 4), (torch.bfloat16, 2)):
     e1.record(); e1.synchronize()
     t = e0.elapsed_time(e1) * 1e-3 / n
     byts = B * C * T * (4 + osz)
-    print(f"filter {out_dtype}: {t*1e6:.1f} us per call (incl. basis kernel), {byts/t/1e9:.0f} GB/s algorithmic", flush=True)
+    print(f"filter {out_dtype}: {t*1e6:.1f} us per call, {byts/t/1e9:.0f} GB/s algorithmic", flush=True)
+for tm in (False, True):
+    for _ in range(3):
+        cabi.eeg_bandpass_znorm(x[0], sos, time_major=tm)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for i in range(40):
+        cabi.eeg_bandpass_znorm(x[i % 4], sos, time_major=tm)
+    e1.record(); e1.synchronize()
+    t = e0.elapsed_time(e1) * 1e-3 / 40
+    print(f"filter f32 time_major={tm}: {t*1e6:.1f} us per call, {B*C*T*8/t/1e9:.0f} GB/s algorithmic", flush=True)

@@ -19,7 +19,7 @@ i=0
 for g in "${groups[@]}"; do
   d=gpurun_out/pmcc_$i
   rm -rf $d
-  if rocprofv3 --pmc $g --kernel-trace --output-format csv -d $d -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-retrieval --no-f32-line "$@" > $d.log 2>&1; then
+  if rocprofv3 --pmc $g --kernel-trace --output-format csv -d $d -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-retrieval --no-f32-line --no-parity "$@" > $d.log 2>&1; then
     echo "$d" >> gpurun_out/pmcc_index.txt
     echo "pass $i ok: $g"
   else
@@ -32,7 +32,7 @@ import csv, glob, json, sys, collections
 names = ["lstm_bwd_persist_kernel", "lstm_fwd_persist_kernel", "gemm_nt_256_kernel", "gemm_nt_dma_kernel", "gemm_tn_256_kernel",
          "gemm_tn_bf16_kernel", "gemm_tn_n128_kernel", "eeg_filter_scan_kernel", "lstm_cell_fwd_il_kernel", "lstm_cell_bwd_il_kernel",
          "rmsprop_flat_kernel"]
-res = {"command": "rocprofv3 --pmc <group> --kernel-trace -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-retrieval --no-f32-line (one pass per group)",
+res = {"command": "rocprofv3 --pmc <group> --kernel-trace -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-retrieval --no-f32-line --no-parity (one pass per group)",
        "note": "per-launch averages; SQ_* cycle counters other than SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES count quad-cycles summed over waves; "
                "GRBM_GUI_ACTIVE is summed over the 8 XCDs", "kernels": {}}
 for d in open("gpurun_out/pmcc_index.txt").read().split():
@@ -65,6 +65,9 @@ for n, e in res["kernels"].items():
     if e.get("SQ_LDS_IDX_ACTIVE"):
         der["lds_bank_conflict_share"] = e.get("SQ_LDS_BANK_CONFLICT", 0.0) / e["SQ_LDS_IDX_ACTIVE"]
     e["derived"] = der
+sys.path.insert(0, ".")
+import bench
+res["csrc_sha16"] = bench.csrc_sha16()     # bench.py drops these values once the kernel sources differ
 json.dump(res, open(sys.argv[1], "w"), indent=1)
 for n, e in res["kernels"].items():
     print(n, {k: (round(v, 4) if isinstance(v, float) else v) for k, v in e["derived"].items()})

@@ -6,11 +6,11 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 out=${1:-gpurun_out/pmc_traffic.json}
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf gpurun_out/pmcb_$c
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmcb_$c -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-retrieval --no-f32-line > gpurun_out/pmcb_$c.log 2>&1 || { echo "pass $c failed"; tail -5 gpurun_out/pmcb_$c.log; exit 1; }
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmcb_$c -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-retrieval --no-f32-line --no-parity > gpurun_out/pmcb_$c.log 2>&1 || { echo "pass $c failed"; tail -5 gpurun_out/pmcb_$c.log; exit 1; }
 done
 python3 - "$out" <<'PY'
 import csv, glob, json, sys, collections
-res = {"command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE (separate passes) --kernel-trace -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-retrieval --no-f32-line",
+res = {"command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE (separate passes) --kernel-trace -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-retrieval --no-f32-line --no-parity",
        "units": "counter values are KiB per dispatch; corrected = (2*FETCH_SIZE + WRITE_SIZE)*1024 bytes (gfx950: FETCH_SIZE counts 128-B requests as 64 B)",
        "kernels": {}}
 names = ["lstm_bwd_persist_kernel", "lstm_fwd_persist_kernel", "gemm_nt_256_kernel", "gemm_nt_dma_kernel", "gemm_nt_bf16_kernel",
@@ -32,6 +32,9 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
 for n, e in res["kernels"].items():
     if "FETCH_SIZE_KB_avg_per_launch" in e and "WRITE_SIZE_KB_avg_per_launch" in e:
         e["hbm_bytes_per_launch_corrected"] = (2 * e["FETCH_SIZE_KB_avg_per_launch"] + e["WRITE_SIZE_KB_avg_per_launch"]) * 1024
+sys.path.insert(0, ".")
+import bench
+res["csrc_sha16"] = bench.csrc_sha16()     # bench.py drops these values once the kernel sources differ
 json.dump(res, open(sys.argv[1], "w"), indent=1)
 for n, e in res["kernels"].items():
     print(n, {k: round(v, 1) if isinstance(v, float) else v for k, v in e.items()})

@@ -10,7 +10,7 @@ mkdir -p $out
 python3 bench.py > $out/bench.json 2> $out/bench.err
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 rm -rf $out/prof
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-retrieval --no-f32-line > $out/bench_under_rocprof.json 2> $out/prof.log
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-retrieval --no-f32-line --no-parity > $out/bench_under_rocprof.json 2> $out/prof.log
 cp $(find $out/prof -name "*kernel_stats.csv" | head -1) $out/bench_kernel_stats.csv
 cp $(find $out/prof -name "*kernel_trace.csv" | head -1) $out/kernel_trace.csv
 rm -rf $out/prof
