@@ -25,18 +25,49 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
-def build_parser():
+class Flavour:
+    """What differs between the reference's two trainers of this loop.  `perils` = LstmDistillFromDinoV2Train.py
+    (RMSprop 1e-3 :329, Model(128, 96, 2, include_top=True) + FeatureDistributionLoss :323-365, ONE checkpoint name
+    :414,419); `spampinato` = LstmDistillFromDinoV2TrainSpampinato.py (AdamW 1e-4 :378, Model(128, 128, layers=4,
+    include_top=False) :368, loss_fn_kd with alpha / temperature from --hyperprams :107-121,288-296, weights-only resume
+    from --custom_model_weights when the file exists :369-371, first best checkpoint lstm_dinov2_epoch_{E}_best_loss.pth
+    then lstm_dinov2_epochs_{EPOCHS}_best_loss.pth :467-475, utils/EEGDataset.py with subject + split file :310-317)."""
+
+    def __init__(self, name, learning_rate, num_epochs, eeg_dataset, eeg_dataset_split, hyperprams, optimizer, loss,
+                 hidden_size, lstm_layers, dataset_flavour):
+        self.name, self.learning_rate, self.num_epochs = name, learning_rate, num_epochs
+        self.eeg_dataset, self.eeg_dataset_split, self.hyperprams = eeg_dataset, eeg_dataset_split, hyperprams
+        self.optimizer, self.loss, self.hidden_size, self.lstm_layers = optimizer, loss, hidden_size, lstm_layers
+        self.dataset_flavour = dataset_flavour
+
+    def checkpoint_path(self, log_dir, epoch, epochs, first_best):
+        if self.name == "spampinato":
+            return (f"{log_dir}/lstm_dinov2_epoch_{epoch}_best_loss.pth" if first_best
+                    else f"{log_dir}/lstm_dinov2_epochs_{epochs}_best_loss.pth")
+        return f"{log_dir}/lstm_dinov2_best_loss.pth"
+
+
+PERILS = Flavour("perils", 0.001, 100, "./data/eeg/theperils/spampinato-1-IMAGE_BLOCK_RAW_with_mean_std.pth",
+                 "./data/eeg/block_splits_by_image_all.pth",
+                 "{'ce_loss_weight': 0.50, 'soft_target_loss_weight':0.50,'alpha': 1,'temperature':2}",
+                 "rmsprop", "featdist", 96, 2, "perils")
+SPAMPINATO = Flavour("spampinato", 0.0001, 200, "./data/eeg/spampinato/eeg_signals_raw_with_mean_std.pth",
+                     "./data/eeg/spampinato/block_splits_by_image_all.pth",
+                     "{'ce_loss_weight': 0.50, 'soft_target_loss_weight':0.50,'alpha': 0,'temperature':2}",
+                     "adamw", "kd", 128, 4, "spampinato")
+
+
+def build_parser(flavour=PERILS):
     p = argparse.ArgumentParser('LSTM distillation from DINOv2 embeddings (MI355X).')
-    p.add_argument('--learning_rate', type=float, default=0.001)
-    p.add_argument('--num_epochs', type=int, default=100)
+    p.add_argument('--learning_rate', type=float, default=flavour.learning_rate)
+    p.add_argument('--num_epochs', type=int, default=flavour.num_epochs)
     p.add_argument('--batch_size', type=int, default=16, help='per-process batch size')
     p.add_argument('--log_dir', type=str, default='./logs/DinoV2LstmDistillv2sdsad/')
     p.add_argument('--gallery_subject', type=int, default=1, choices=[0, 1, 2, 3, 4, 5, 6])
     p.add_argument('--query_subject', type=int, default=1, choices=[0, 1, 2, 3, 4, 5, 6])
-    p.add_argument('--eeg_dataset', type=str,
-                   default="./data/eeg/theperils/spampinato-1-IMAGE_BLOCK_RAW_with_mean_std.pth")
+    p.add_argument('--eeg_dataset', type=str, default=flavour.eeg_dataset)
     p.add_argument('--images_root', type=str, default="./data/images/imageNet_images")
-    p.add_argument('--eeg_dataset_split', type=str, default="./data/eeg/block_splits_by_image_all.pth")
+    p.add_argument('--eeg_dataset_split', type=str, default=flavour.eeg_dataset_split)
     p.add_argument('--mode', type=str, default="train")
     p.add_argument('--custom_model_weights', type=str, default="")
     p.add_argument('--search_gallery', type=str, default="train")
@@ -44,19 +75,21 @@ def build_parser():
     p.add_argument('--topK', type=int, default=5)
     p.add_argument('--gallery_tranformation_type', type=str, default="eeg2eeg", choices=["img", "img2eeg", "eeg", "eeg2eeg"])
     p.add_argument('--query_tranformation_type', type=str, default="eeg2eeg", choices=["img", "img2eeg", "eeg", "eeg2eeg"])
-    p.add_argument('--hyperprams', type=str,
-                   default="{'ce_loss_weight': 0.50, 'soft_target_loss_weight':0.50,'alpha': 1,'temperature':2}")
+    p.add_argument('--hyperprams', type=str, default=flavour.hyperprams)
     p.add_argument('--seed', default=43, type=int)
     p.add_argument('--num_workers', default=4, type=int)
     p.add_argument("--dist_url", default="env://", type=str)
     p.add_argument("--local_rank", default=0, type=int)
     # --- additions (SURVEY.md section 5 "Config / flags") ---
     p.add_argument('--synthetic', type=int, default=0, help='train on N synthetic 128x500 segments')
+    p.add_argument('--synthetic_samples', type=int, default=440 if flavour.name == "spampinato" else 500,
+                   help='samples per synthetic segment (BASELINE.json: 128 x 500; Spampinato split 128 x 440)')
     p.add_argument('--teacher_features', type=str, default="", help='.npy [N,D] precomputed frozen-teacher embeddings')
-    p.add_argument('--hidden_size', type=int, default=96, help='lstm_size (reference call site: 96)')
-    p.add_argument('--lstm_layers', type=int, default=2)
+    p.add_argument('--hidden_size', type=int, default=flavour.hidden_size, help='lstm_size (reference call sites: 96 / 128)')
+    p.add_argument('--lstm_layers', type=int, default=flavour.lstm_layers)
     p.add_argument('--output_size', type=int, default=384)
-    p.add_argument('--loss', type=str, default="featdist", choices=["featdist", "cosine", "kd", "barlow"])
+    p.add_argument('--loss', type=str, default=flavour.loss, choices=["featdist", "cosine", "kd", "barlow"])
+    p.add_argument('--optimizer', type=str, default=flavour.optimizer, choices=["rmsprop", "adamw", "adam", "lars"])
     p.add_argument('--dtype', type=str, default="bf16", choices=["bf16", "f32"])
     p.add_argument('--fs', type=float, default=1000.0, help='sampling rate for the band-pass design')
     p.add_argument('--filter_order', type=int, default=3, choices=[0, 3, 4, 5], help='0 = no band-pass')
@@ -89,14 +122,14 @@ def init_distributed():
     return 0, 1, 0
 
 
-def main(argv=None):
+def main(argv=None, flavour=PERILS):
     from cerebralsignalnetworks_amd import Model, EEGFilters
     from cerebralsignalnetworks_amd.dataset import EEGDataset
     from cerebralsignalnetworks_amd.retrieval import evaluate_full
     from cerebralsignalnetworks_amd.trainer import DistillTrainer, shard_indices, split_indices
     from cerebralsignalnetworks_amd.losses import HyperParams
 
-    FLAGS, _unparsed = build_parser().parse_known_args(argv)
+    FLAGS, _unparsed = build_parser(flavour).parse_known_args(argv)
     rank, world, local = init_distributed()
     is_main = rank == 0
     if is_main:
@@ -104,16 +137,20 @@ def main(argv=None):
     os.makedirs(FLAGS.log_dir, exist_ok=True)
     hyper = ast.literal_eval(FLAGS.hyperprams)
     kd = _KdParams()
-    kd.alpha = hyper.get("alpha", kd.alpha)
+    kd.alpha = hyper.get("alpha", kd.alpha)                 # (Parameters.alpha / .temperature of the Spampinato script, :288-296)
     kd.temperature = hyper.get("temperature", kd.temperature)
     torch.manual_seed(FLAGS.seed)
     device = torch.device("cuda", local)
 
     if FLAGS.synthetic:
-        dataset = EEGDataset(synthetic=FLAGS.synthetic, time_low=0, time_high=500, seed=FLAGS.seed, device=device,
+        dataset = EEGDataset(synthetic=FLAGS.synthetic, synthetic_samples=FLAGS.synthetic_samples, time_low=0,
+                             time_high=FLAGS.synthetic_samples, seed=FLAGS.seed, device=device,
                              feature_dim=FLAGS.output_size, compat_label_bug=FLAGS.compat_label_bug)
     else:
-        dataset = EEGDataset(eeg_signals_path=FLAGS.eeg_dataset, eeg_splits_path=None, imagesRoot=FLAGS.images_root,
+        spamp = flavour.dataset_flavour == "spampinato"       # utils/EEGDataset.py: subject + split file (:310-317)
+        dataset = EEGDataset(eeg_signals_path=FLAGS.eeg_dataset, imagesRoot=FLAGS.images_root,
+                             eeg_splits_path=FLAGS.eeg_dataset_split if spamp and os.path.exists(FLAGS.eeg_dataset_split) else None,
+                             subject=FLAGS.gallery_subject if spamp else 1, flavour=flavour.dataset_flavour,
                              time_low=FLAGS.time_low, time_high=FLAGS.time_high, device=device,
                              compat_label_bug=FLAGS.compat_label_bug)
         if not FLAGS.teacher_features:
@@ -129,11 +166,16 @@ def main(argv=None):
     include_top = FLAGS.loss == "featdist"
     model = Model(input_size=C, lstm_size=FLAGS.hidden_size, lstm_layers=FLAGS.lstm_layers,
                   output_size=features_length, include_top=include_top, compute_dtype=dtype).to(device)
-    if FLAGS.custom_model_weights:
+    if flavour.name == "spampinato":
+        if os.path.exists(FLAGS.custom_model_weights):           # :369-371: resume only if the file is there, strict keys
+            model.load_state_dict(torch.load(FLAGS.custom_model_weights, map_location="cpu", weights_only=True))
+            if is_main:
+                print(f"loaded  {FLAGS.custom_model_weights}")
+    elif FLAGS.custom_model_weights:
         sd = torch.load(FLAGS.custom_model_weights, map_location="cpu", weights_only=True)
         model.load_state_dict(sd, strict=False)
     sos = EEGFilters(FLAGS.fs, order=FLAGS.filter_order).sos if FLAGS.filter_order else None
-    trainer = DistillTrainer(model, sos, loss=FLAGS.loss, lr=FLAGS.learning_rate, optimizer="rmsprop",
+    trainer = DistillTrainer(model, sos, loss=FLAGS.loss, lr=FLAGS.learning_rate, optimizer=FLAGS.optimizer,
                              nepochs=max(FLAGS.num_epochs, HyperParams.warmup_teacher_temp_epochs + 1), kd_params=kd)
 
     def batches(idx, epoch, shuffle):
@@ -166,14 +208,15 @@ def main(argv=None):
                                   labels_of(val_idx), dataset)
                 print(f"Overall Recall :{r['Recall_Total']} Overall Precision: {r['Precision_Total']} top1: {r['top1']:.4f}")
                 if best_val_loss is None or val_epoch_loss < best_val_loss:
+                    ckpt = flavour.checkpoint_path(FLAGS.log_dir, EPOCH, FLAGS.num_epochs, best_val_loss is None)
                     best_val_loss, best_val_loss_epoch = val_epoch_loss, EPOCH
-                    torch.save(model.state_dict(), f"{FLAGS.log_dir}/lstm_dinov2_best_loss.pth")
+                    torch.save(model.state_dict(), ckpt)
                 print(f"EPOCH {EPOCH} train_loss: {round(epoch_loss, 6)} val_loss: {round(val_epoch_loss, 6)} "
                       f"T: {HyperParams.T} best val loss: {best_val_loss} on epoch: {best_val_loss_epoch}")
         elif is_main:
             print(f"EPOCH {EPOCH} train_loss: {round(epoch_loss, 6)} T: {HyperParams.T}")
         history.append(epoch_loss)
-    if is_main and best_val_loss is None:
+    if is_main and best_val_loss is None and flavour.name == "perils":
         torch.save(model.state_dict(), f"{FLAGS.log_dir}/lstm_dinov2_best_loss.pth")
     if world > 1:
         dist.barrier()

@@ -21,8 +21,8 @@ struct SosParams {
   double c[8][5];  // b0 b1 b2 a1 a2, normalised by a0
 };
 
-template <int NSEC>
-__host__ __device__ __forceinline__ double biquad_cascade(double v, const SosParams& p, double (&s1)[8], double (&s2)[8]) {
+template <int NSEC, typename Params>      // Params: SosParams, in whatever address space it lives (kernel-argument segment in the scan kernel)
+__host__ __device__ __forceinline__ double biquad_cascade(double v, const Params& p, double (&s1)[8], double (&s2)[8]) {
 #pragma unroll
   for (int s = 0; s < NSEC; ++s) {
     const double y = fma(p.c[s][0], v, s1[s]);
@@ -100,7 +100,8 @@ __global__ void __launch_bounds__(64) eeg_filter_rows_kernel(const float* __rest
 // transposed store lives in registers, so the kernel runs at the speed of its loads and stores.
 //   A workgroup (512 threads) takes 32 consecutive rows (channels); the 16 lanes of a DPP row are the
 //   16 chunks of 32 samples of ONE row.  Thread (row, chunk):
-//     1. loads its 32 samples (8 x 16 B; the four rows of a wave are one contiguous 8 KB run of x),
+//     1. gets its 32 samples: the four rows of a wave are one contiguous run of x, loaded 1 KB per instruction and
+//        passed through the wave's own corner of LDS (a lane-strided direct load thrashed L1),
 //     2. filters them from a ZERO state in float64 (the poles of this band sit at radius 0.9997:
 //        float32 state costs 2e-4) -> zero-state response + the chunk's end state e_k,
 //     3. the cascade is linear, so the true state at the end of chunk k is S_k = A S_{k-1} + e_k with
@@ -123,7 +124,7 @@ static constexpr int kScanRows = 32, kScanChunks = 16, kScanLen = 32;
 template <int NSEC>
 struct ScanBasis {
   static constexpr int NS = NSEC > 0 ? 2 * NSEC : 1;
-  double phi[NS][kScanLen];    // [state component][n]
+  double phi[kScanLen][NS];    // [n][state component]: read in this order by the kernel (sequential scalar loads)
   double apow[4][NS][NS];      // apow[m][j][i] = component j of the state 32 * 2^m steps after e_i
 };
 
@@ -136,7 +137,7 @@ static void fill_scan_basis(const SosParams& p, ScanBasis<NSEC>* b) {
       if (i == 2 * s) s1[s] = 1.0;
       if (i == 2 * s + 1) s2[s] = 1.0;
     }
-    for (int n = 0; n < kScanLen; ++n) b->phi[i][n] = NSEC > 0 ? biquad_cascade<NSEC>(0.0, p, s1, s2) : 0.0;
+    for (int n = 0; n < kScanLen; ++n) b->phi[n][i] = NSEC > 0 ? biquad_cascade<NSEC>(0.0, p, s1, s2) : 0.0;
     for (int j = 0; j < NS; ++j) b->apow[0][j][i] = 0.0;
     for (int s = 0; s < NSEC; ++s) {
       b->apow[0][2 * s][i] = s1[s];
@@ -163,8 +164,8 @@ __device__ __forceinline__ double dpp_f64(double v) {
 #define CSN_DPP_ROW_SHR(n) (0x110 | (n))
 #define CSN_DPP_ROW_ROR(n) (0x120 | (n))
 
-template <int NSEC, int M>
-__device__ __forceinline__ void scan_step(double (&sv)[ScanBasis<NSEC>::NS], const ScanBasis<NSEC>& bs) {
+template <int NSEC, int M, typename Basis>
+__device__ __forceinline__ void scan_step(double (&sv)[ScanBasis<NSEC>::NS], const Basis& bs) {
   constexpr int NS = ScanBasis<NSEC>::NS;
   double sh[NS];
 #pragma unroll
@@ -194,120 +195,214 @@ __device__ __forceinline__ void store_quad<bf16_t>(bf16_t* dst, const float4& v)
   *reinterpret_cast<bf16x4*>(dst) = o;
 }
 
+// input staging: [row][chunk] blocks of 32 samples, block pitch 36 dwords -- the 16 lanes of a ds_read_b128 group (16
+// different chunk indices, whatever their rows: the row pitch is 0 mod 64 banks) land on 16 different 4-bank slots
+static constexpr int kScanPitch = 36;
+static constexpr int kScanLdsBytes = kScanRows * kScanChunks * kScanPitch * 4;      // 73 728 B (>= the 64 KB output tile)
+
+// ALL kernel arguments in one struct = the kernarg segment from offset 0: the tile loop re-reads the coefficients through
+// a laundered pointer to that segment, so the compiler cannot hoist the ~340 coefficient loads of the basis out of the
+// loop (it did: 800 - 1600 SGPRs spilled to VGPR lanes, those spilled to scratch).
+template <int NSEC>
+struct ScanArgs {
+  const float* x;
+  void* y;
+  int B, C, T, ddof, time_major, pad_;
+  SosParams p;
+  ScanBasis<NSEC> bs;
+};
+template <int NSEC>
+using ScanArgsK = const __attribute__((address_space(4))) ScanArgs<NSEC>;
+
 template <int NSEC, typename OutT>
-__global__ void __launch_bounds__(512, 4)
-eeg_filter_scan_kernel(const float* __restrict__ x, OutT* __restrict__ y, int B, int C, int T, const SosParams p,
-                       const ScanBasis<NSEC> bs, int ddof, int time_major) {
+__global__ void __launch_bounds__(512, 4) eeg_filter_scan_kernel(const ScanArgs<NSEC> args) {
   constexpr int NS = ScanBasis<NSEC>::NS;
-  __shared__ __attribute__((aligned(16))) float tile[kScanChunks * kScanLen * kScanRows];     // [t][channel], 64 KB
+  extern __shared__ __attribute__((aligned(16))) float tile[];     // input staging, then [t][channel] (64 KB) for the store
+  const float* __restrict__ x = args.x;
+  OutT* __restrict__ y = reinterpret_cast<OutT*>(args.y);
+  const int B = args.B, C = args.C, T = args.T, ddof = args.ddof, time_major = args.time_major;
   const int tid = threadIdx.x;
   const int k = tid & 15, rl = tid >> 4;
   const int64_t rows_total = (int64_t)B * C;
-  const int64_t row0 = (int64_t)blockIdx.x * kScanRows;
-  const int64_t row = row0 + rl;
-  const bool rok = row < rows_total;
-  const int t0 = k * kScanLen;
+  // Local time u = t + pad, pad = 512 - T: the row is RIGHT-aligned in its 16 chunks, the missing samples are leading
+  // zeros.  Zero input from zero state gives zero output and zero state, so neither the cascade nor the statistics
+  // need a mask (with the row left-aligned, samples past T had to be masked out of both: a compare and two selects per
+  // sample), and only the store looks at u >= pad.
+  const int u0 = k * kScanLen;
+  const int lane = tid & 63, wrow = (tid >> 6) * 4;               // first of this wave's rows inside the workgroup
+  const int q4 = T >> 2;                                          // float4 per row
+  const int pad = kScanChunks * kScanLen - T, pq = pad >> 2;      // leading zeros per row (floats, float4s)
+  const int ntiles = (int)((rows_total + kScanRows - 1) / kScanRows);
 
-  // ---- 1: this thread's 32 samples (zeros beyond T / beyond the last row)
-  double v[kScanLen];
-  {
-    const float* src = x + row * (int64_t)T + t0;
-    if ((T & 3) == 0) {
+  // ---- 1a: a wave's four rows are one contiguous run of 4 T floats (T % 4 == 0): loaded 1 KB per instruction.
+  // (Loading a thread's 32 samples straight into its registers -- 64 lanes x 16 B at a 128-byte stride, eight
+  // instructions over the same 64 lines -- thrashed L1: 8 x the L2 -> L1 traffic, 56 us per 256 segments.)
+  // Where float4 `idx` of the wave's run goes in the staging area (tile-invariant: kept).  The 512 float4 slots of the
+  // eight load instructions are exactly the wave's 4 rows x 16 chunks x 8 float4: the 4 q4 slots of the run carry data,
+  // the 4 pq slots behind it write the rows' leading zeros -- every position is written for every tile.
+  int sa[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int idx = lane + 64 * j;
+    const bool data = idx < 4 * q4;
+    const int z = data ? idx : idx - 4 * q4;
+    const int per = data ? q4 : pq;
+    const int r = (z >= per) + (z >= 2 * per) + (z >= 3 * per);
+    const int u = 4 * (z - r * per) + (data ? pad : 0);
+    sa[j] = ((wrow + r) * kScanChunks + (u >> 5)) * kScanPitch + (u & 31);
+  }
+  f32x4 g[8];                 // (native vectors: an array of HIP's float4 structs was kept in scratch memory)
+  auto request = [&](int tl) {
+    // C % 4 == 0 (the launcher sends everything else to the row-walking kernel): a wave's four rows exist or none does;
+    // a wave beyond the last row loads rows 0..3 again -- nothing of it is stored
+    const int64_t r0 = (int64_t)tl * kScanRows + wrow;
+    const f32x4* src = reinterpret_cast<const f32x4*>(x + (r0 < rows_total ? r0 : 0) * (int64_t)T);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int idx = lane + 64 * j;
+      const f32x4 got = src[idx < 4 * q4 ? idx : 4 * q4 - 1];
+      g[j] = idx < 4 * q4 ? got : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  request(blockIdx.x);
+  // store phase: this thread writes channel quad q of time steps (tid >> 3) + 64 it
+  const int sq = tid & 7, st0 = tid >> 3;
+  const int64_t tstride = time_major ? (int64_t)B * C : (int64_t)C;
+
+  // The workgroup walks tiles blockIdx.x, + gridDim.x, ...: the NEXT tile's loads are in flight while this one is
+  // filtered, and this one's stores drain under the next one's arithmetic.
+  for (int tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
+    const int64_t row0 = (int64_t)tl * kScanRows;
+    ScanArgsK<NSEC>* ka = (ScanArgsK<NSEC>*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(ka));            // opaque per tile: coefficient loads stay inside the loop, next to their uses
+    const auto& p = ka->p;
+    const auto& bs = ka->bs;
+    // ---- 1b: through the wave's own part of LDS (no workgroup barrier: written and read by this wave only) into this
+    // thread's 32 samples (float32 between the phases: 32 registers; every phase computes in float64)
+    float v[kScanLen];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) *reinterpret_cast<f32x4*>(__builtin_assume_aligned(tile + sa[j], 16)) = g[j];
+    __builtin_amdgcn_sched_barrier(0);
+    if (tl + (int)gridDim.x < ntiles) request(tl + gridDim.x);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_wave_barrier();
+    {
+      const float* mine = reinterpret_cast<const float*>(__builtin_assume_aligned(tile + (rl * kScanChunks + k) * kScanPitch, 16));
 #pragma unroll
       for (int i = 0; i < kScanLen / 4; ++i) {
-        float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (rok && t0 + 4 * i < T) q = *reinterpret_cast<const float4*>(src + 4 * i);
-        v[4 * i + 0] = (double)q.x; v[4 * i + 1] = (double)q.y; v[4 * i + 2] = (double)q.z; v[4 * i + 3] = (double)q.w;
+        const f32x4 q = *reinterpret_cast<const f32x4*>(mine + 4 * i);
+        v[4 * i + 0] = q[0]; v[4 * i + 1] = q[1]; v[4 * i + 2] = q[2]; v[4 * i + 3] = q[3];
+      }
+    }
+
+    double sum = 0.0, sumsq = 0.0;
+    if constexpr (NSEC > 0) {
+      // ---- 2: zero-state response in place, end state
+      double sv[NS];
+      {
+        double s1[8], s2[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) { s1[s] = 0.0; s2[s] = 0.0; }
+#pragma unroll
+        for (int j = 0; j < kScanLen; ++j) {
+          v[j] = (float)biquad_cascade<NSEC>((double)v[j], p, s1, s2);
+          if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);      // (bounds what the scheduler keeps in flight: 128 registers)
+        }
+#pragma unroll
+        for (int s = 0; s < NSEC; ++s) { sv[2 * s] = s1[s]; sv[2 * s + 1] = s2[s]; }
+      }
+      // ---- 3: inclusive scan of the end states over the row's 16 chunks; this chunk starts from S_{k-1}
+      // (scheduling fences: left alone, the compiler requests the coefficients of all steps / samples at once and
+      // spills 100 - 200 SGPRs to VGPR lanes, each use then a v_readlane)
+      __builtin_amdgcn_sched_barrier(0);
+      scan_step<NSEC, 0>(sv, bs);
+      __builtin_amdgcn_sched_barrier(0);
+      scan_step<NSEC, 1>(sv, bs);
+      __builtin_amdgcn_sched_barrier(0);
+      scan_step<NSEC, 2>(sv, bs);
+      __builtin_amdgcn_sched_barrier(0);
+      scan_step<NSEC, 3>(sv, bs);
+      __builtin_amdgcn_sched_barrier(0);
+      double s0[NS];
+#pragma unroll
+      for (int i = 0; i < NS; ++i) s0[i] = dpp_f64<CSN_DPP_ROW_SHR(1)>(sv[i]);
+      // ---- 4: homogeneous response, row statistics (the leading zeros stay zeros: S_{k-1} is zero there)
+#pragma unroll
+      for (int j = 0; j < kScanLen; ++j) {
+        double c = (double)v[j];
+#pragma unroll
+        for (int i = 0; i < NS; ++i) c = fma(s0[i], bs.phi[j][i], c);
+        v[j] = (float)c;
+        sum += c;
+        sumsq = fma(c, c, sumsq);
+        if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);
       }
     } else {
 #pragma unroll
-      for (int j = 0; j < kScanLen; ++j) v[j] = (rok && t0 + j < T) ? (double)src[j] : 0.0;
+      for (int j = 0; j < kScanLen; ++j) {
+        const double m = (double)v[j];
+        sum += m;
+        sumsq = fma(m, m, sumsq);
+        if ((j & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+      }
     }
-  }
+    sum = row16_sum(sum);
+    sumsq = row16_sum(sumsq);
+    const double mean = sum / (double)T;
+    const double inv = 1.0 / sqrt((sumsq - sum * mean) / (double)(T - ddof));
 
-  if constexpr (NSEC > 0) {
-    // ---- 2: zero-state response in place, end state
-    double sv[NS];
+    // ---- 5: normalise, transpose through LDS, store channel-fastest
+    __syncthreads();          // every wave has read its staged input: the tile is reused for the output
     {
-      double s1[8], s2[8];
+      float* dst = tile + u0 * kScanRows + ((rl + 4 * (k & 7)) & 31);
 #pragma unroll
-      for (int s = 0; s < 8; ++s) { s1[s] = 0.0; s2[s] = 0.0; }
-#pragma unroll
-      for (int j = 0; j < kScanLen; ++j) v[j] = biquad_cascade<NSEC>(v[j], p, s1, s2);
-#pragma unroll
-      for (int s = 0; s < NSEC; ++s) { sv[2 * s] = s1[s]; sv[2 * s + 1] = s2[s]; }
-    }
-    // ---- 3: inclusive scan of the end states over the row's 16 chunks; this chunk starts from S_{k-1}
-    scan_step<NSEC, 0>(sv, bs);
-    scan_step<NSEC, 1>(sv, bs);
-    scan_step<NSEC, 2>(sv, bs);
-    scan_step<NSEC, 3>(sv, bs);
-    double s0[NS];
-#pragma unroll
-    for (int i = 0; i < NS; ++i) s0[i] = dpp_f64<CSN_DPP_ROW_SHR(1)>(sv[i]);
-    // ---- 4a: homogeneous response
-#pragma unroll
-    for (int j = 0; j < kScanLen; ++j)
-#pragma unroll
-      for (int i = 0; i < NS; ++i) v[j] = fma(s0[i], bs.phi[i][j], v[j]);
-  }
-
-  // ---- 4b: row statistics (samples beyond T do not count)
-  double sum = 0.0, sumsq = 0.0;
-#pragma unroll
-  for (int j = 0; j < kScanLen; ++j) {
-    const double m = (t0 + j < T) ? v[j] : 0.0;
-    sum += m;
-    sumsq = fma(m, m, sumsq);
-  }
-  sum = row16_sum(sum);
-  sumsq = row16_sum(sumsq);
-  const double mean = sum / (double)T;
-  const double inv = 1.0 / sqrt((sumsq - sum * mean) / (double)(T - ddof));
-
-  // ---- 5: normalise, transpose through LDS, store channel-fastest
-  {
-    const int col = (rl + 4 * (k & 7)) & 31;
-#pragma unroll
-    for (int j = 0; j < kScanLen; ++j) tile[(t0 + j) * kScanRows + col] = (float)((v[j] - mean) * inv);
-  }
-  __syncthreads();
-  const bool quad_ok = (C & 3) == 0;            // the 4 rows of a quad are 4 consecutive channels of one segment
-#pragma unroll
-  for (int it = 0; it < kScanChunks * kScanLen * 8 / 512; ++it) {
-    const int idx = it * 512 + tid;
-    const int q = idx & 7, t = idx >> 3;
-    if (t >= T) continue;
-    const float4 o = *reinterpret_cast<const float4*>(tile + t * kScanRows + ((4 * q + 4 * ((t >> 5) & 7)) & 31));
-    const int64_t r4 = row0 + 4 * q;
-    if (quad_ok) {
-      if (r4 >= rows_total) continue;
-      const int b = (int)(r4 / C), ch = (int)(r4 % C);
-      OutT* dst = y + (time_major ? ((int64_t)t * B + b) * C + ch : ((int64_t)b * T + t) * C + ch);
-      store_quad<OutT>(dst, o);
-    } else {
-      const float ov[4] = {o.x, o.y, o.z, o.w};
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        if (r4 + e >= rows_total) continue;
-        const int b = (int)((r4 + e) / C), ch = (int)((r4 + e) % C);
-        y[time_major ? ((int64_t)t * B + b) * C + ch : ((int64_t)b * T + t) * C + ch] = from_f32<OutT>(ov[e]);
+      for (int j = 0; j < kScanLen; ++j) {
+        dst[j * kScanRows] = (float)(((double)v[j] - mean) * inv);
+        if ((j & 7) == 7) __builtin_amdgcn_sched_barrier(0);
       }
     }
+    __syncthreads();
+    {
+      const int64_t r4 = row0 + 4 * sq;                             // 4 consecutive channels of one segment (C % 4 == 0)
+      if (r4 < rows_total) {
+        const unsigned bq = (unsigned)(r4 / (unsigned)C);           // (rows_total < 2^32: B, C are ints and the tile fits HBM)
+        const unsigned ch = (unsigned)r4 - bq * (unsigned)C;
+        OutT* dst = y + (time_major ? (int64_t)bq * C + ch : (int64_t)bq * T * C + ch) + (st0 - pad) * tstride;
+        const float* src = tile + st0 * kScanRows;
+#pragma unroll
+        for (int it = 0; it < kScanChunks * kScanLen / 64; ++it) {
+          const int u = st0 + 64 * it;                               // local time; chunk u >> 5 = 2 it + (st0 >> 5)
+          if (u >= pad)
+            store_quad<OutT>(dst + (int64_t)(64 * it) * tstride,
+                             *reinterpret_cast<const float4*>(__builtin_assume_aligned(
+                                 src + 64 * it * kScanRows + ((4 * sq + 4 * ((u >> 5) & 7)) & 31), 16)));
+        }
+      }
+    }
+    __syncthreads();          // the output tile has been read: the next tile's staging may overwrite it
   }
 }
 
 template <int NSEC>
 static int launch_scan(const float* x, void* y, int B, int C, int T, const SosParams& p, int ddof, int out_dtype,
                        int time_major, hipStream_t st) {
-  ScanBasis<NSEC> bs;
-  fill_scan_basis<NSEC>(p, &bs);
+  ScanArgs<NSEC> ka;
+  ka.x = x; ka.y = y; ka.B = B; ka.C = C; ka.T = T; ka.ddof = ddof; ka.time_major = time_major; ka.pad_ = 0;
+  ka.p = p;
+  fill_scan_basis<NSEC>(p, &ka.bs);
   const int64_t rows = (int64_t)B * C;
-  const unsigned grid = (unsigned)((rows + kScanRows - 1) / kScanRows);
-  if (out_dtype == CSN_BF16)
-    eeg_filter_scan_kernel<NSEC, bf16_t><<<grid, 512, 0, st>>>(x, (bf16_t*)y, B, C, T, p, bs, ddof, time_major);
-  else
-    eeg_filter_scan_kernel<NSEC, float><<<grid, 512, 0, st>>>(x, (float*)y, B, C, T, p, bs, ddof, time_major);
+  const unsigned ntiles = (unsigned)((rows + kScanRows - 1) / kScanRows);
+  // two workgroups per CU are resident (LDS); each walks its share of the tiles with the next one prefetched
+  int dev = 0, cus = 0;
+  CSN_HIP_CHECK(hipGetDevice(&dev));
+  CSN_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  const unsigned slots = (unsigned)(2 * (cus > 0 ? cus : 256));
+  const unsigned per_wg = (ntiles + slots - 1) / slots;                 // tiles per workgroup
+  const unsigned grid = (ntiles + per_wg - 1) / per_wg;                 // evenly loaded workgroups, <= slots
+  if (int rc = ensure_dyn_lds<&eeg_filter_scan_kernel<NSEC, bf16_t>>(kScanLdsBytes)) return rc;
+  if (int rc = ensure_dyn_lds<&eeg_filter_scan_kernel<NSEC, float>>(kScanLdsBytes)) return rc;
+  if (out_dtype == CSN_BF16) eeg_filter_scan_kernel<NSEC, bf16_t><<<grid, 512, kScanLdsBytes, st>>>(ka);
+  else eeg_filter_scan_kernel<NSEC, float><<<grid, 512, kScanLdsBytes, st>>>(ka);
   CSN_LAUNCH_CHECK();
   return CSN_OK;
 }
@@ -417,7 +512,7 @@ extern "C" int csn_eeg_bandpass_znorm(const float* x, int B, int C, int T, const
     p.c[s][4] = sos[s * 6 + 5] / a0;
   }
   hipStream_t st = as_stream(stream);
-  if (T <= kScanChunks * kScanLen && nsec <= 5 && !options_from_env().filter_v1) {
+  if (T <= kScanChunks * kScanLen && (T & 3) == 0 && (C & 3) == 0 && nsec <= 5 && !options_from_env().filter_v1) {
     switch (nsec) {
       case 0: return launch_scan<0>(x, y, B, C, T, p, ddof, out_dtype, time_major, st);
       case 1: return launch_scan<1>(x, y, B, C, T, p, ddof, out_dtype, time_major, st);

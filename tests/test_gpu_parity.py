@@ -560,6 +560,59 @@ def test_fast_path_matches_oracle_and_v1(cuda, B, T, C, H, L, chunk):
     assert np.abs(fast["y_all"] - slow["y_all"]).max() < 2e-2
 
 
+def test_cli_spampinato_trainer_surface(cuda, tmp_path):
+    """LstmDistillFromDinoV2TrainSpampinato.py (BASELINE.json configs[3]): AdamW 1e-4, Model(128, 128, layers=4,
+    include_top=False), loss_fn_kd with alpha / T from --hyperprams, the two checkpoint names, weights-only resume when
+    the file exists (reference :368-378, :467-475), 128 x 440 synthetic segments."""
+    import LstmDistillFromDinoV2TrainSpampinato as spamp
+    import LstmDistillFromDinoV2Train as loop
+    fl = loop.SPAMPINATO
+    d = loop.build_parser(fl).parse_args([])
+    assert (d.learning_rate, d.num_epochs, d.hidden_size, d.lstm_layers, d.loss, d.optimizer) == (1e-4, 200, 128, 4, "kd", "adamw")
+    assert "'alpha': 0" in d.hyperprams and d.eeg_dataset.endswith("spampinato/eeg_signals_raw_with_mean_std.pth")
+    args = ["--synthetic", "128", "--batch_size", "16", "--num_epochs", "11", "--log_dir", str(tmp_path),
+            "--hyperprams", "{'alpha': 0.3, 'temperature': 2}", "--learning_rate", "0.002"]
+    hist = spamp.main(args)
+    assert len(hist) == 11 and all(np.isfinite(hist)) and hist[-1] < hist[0]           # KD + CE on 40 classes goes down
+    first = os.path.join(str(tmp_path), "lstm_dinov2_epoch_5_best_loss.pth")           # first validated best (epoch 5)
+    assert os.path.exists(first)
+    sd = torch.load(first, weights_only=True)
+    assert sd["lstm.weight_hh_l3"].shape == (512, 128) and sd["fc.weight"].shape == (384, 128) and "class_pred.weight" not in sd
+    # a later improvement goes to the second name (on random labels the validation loss need not improve at epoch 10)
+    assert fl.checkpoint_path("d", 10, 11, False) == "d/lstm_dinov2_epochs_11_best_loss.pth"
+    assert fl.checkpoint_path("d", 5, 11, True) == "d/lstm_dinov2_epoch_5_best_loss.pth"
+    assert loop.PERILS.checkpoint_path("d", 5, 11, True) == loop.PERILS.checkpoint_path("d", 9, 11, False) == "d/lstm_dinov2_best_loss.pth"
+    assert not os.path.exists(os.path.join(str(tmp_path), "lstm_dinov2_best_loss.pth"))
+    later = first
+    # resume: the file exists -> loaded (strict); the first epoch then starts from the trained loss, not from scratch
+    hist2 = spamp.main(args[:-2] + ["--learning_rate", "1e-5", "--num_epochs", "1", "--custom_model_weights", later,
+                                    "--log_dir", str(tmp_path / "resume")])
+    assert hist2[0] < 0.5 * (hist[0] + hist[-1])
+    # a path that does not exist is ignored, as in the reference (os.path.exists guard)
+    hist3 = spamp.main(args[:-2] + ["--num_epochs", "1", "--custom_model_weights", str(tmp_path / "nope.pth"),
+                                    "--log_dir", str(tmp_path / "fresh")])
+    assert abs(hist3[0] - hist[0]) < 0.25 * hist[0]
+    # first step of this configuration against the oracle's loss_fn_kd (same weights, same batch)
+    from cerebralsignalnetworks_amd.dataset import EEGDataset
+    from cerebralsignalnetworks_amd.trainer import DistillTrainer
+    torch.manual_seed(43)
+    ds = EEGDataset(synthetic=64, synthetic_samples=440, time_low=0, time_high=440, seed=43, device=cuda)
+    m = Model(input_size=128, lstm_size=128, lstm_layers=4, output_size=384, include_top=False,
+              compute_dtype=torch.float32).to(cuda)
+    params = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
+    kd = loop._KdParams()
+    kd.alpha, kd.temperature = 0.3, 2
+    sos = EEGFilters(1000, order=3).sos
+    tr = DistillTrainer(m, sos, loss="kd", lr=1e-4, optimizer="adamw", kd_params=kd)
+    assert isinstance(tr.opt, torch.optim.AdamW)
+    idx = torch.arange(16, device=cuda)
+    loss = float(tr.train_step(ds.eeg_all[idx], ds.features_all[idx], ds.labels_dev[idx]))
+    eeg = eeg_filter.eeg_bandpass_znorm(ds.eeg_all[idx].cpu().numpy(), sos)
+    feat = lstm.model_forward(eeg, params, 4)
+    want = losses.loss_fn_kd(feat, ds.labels_dev[idx].cpu().numpy(), ds.features_all[idx].cpu().numpy(), 0.3, 2)
+    assert abs(loss - want) < 1e-4, (loss, want)
+
+
 def test_ring_slots_never_serve_a_stale_step(cuda):
     """The hand-off by data reuses four slab addresses per layer, so a consumer must never be served the PREVIOUS occupant
     of a slot -- data, which the sentinel proof cannot tell from the right step.  The debug library `make tags`
