@@ -44,7 +44,10 @@ __device__ __forceinline__ void beside_gemm_tiles(const BesideGemm& g, char* sme
   const unsigned a_base = (unsigned)((wm * 128 + (lane & 15)) * 128) + ((((unsigned)lane >> 4) ^ sw) << 4);
   const unsigned b_base = 32768u + (unsigned)((wn * 64 + (lane & 15)) * 128) + ((((unsigned)lane >> 4) ^ sw) << 4);
 
-  volatile unsigned* const claim = reinterpret_cast<volatile unsigned*>(smem + kBesideLdsBytes);
+  // (an LDS-address-space pointer: a generic one made this a flat_store / flat_load pair, and FLAT instructions retire
+  // out of order on the counters the counted waits below rely on)
+  typedef __attribute__((address_space(3))) unsigned lds_u32;
+  lds_u32* const claim = (lds_u32*)(__attribute__((address_space(3))) void*)(smem + kBesideLdsBytes);
   for (unsigned lid = worker;; lid += nworkers) {
     __syncthreads();     // every wave has left the previous tile's last stage (and has read the previous claim)
     if (g.counter != nullptr) {

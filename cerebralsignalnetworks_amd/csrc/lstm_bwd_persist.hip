@@ -148,10 +148,10 @@ __global__ void __launch_bounds__(256) lstm_bwd_persist_kernel(PersistBwdArgs a)
           break;
         }
       }
-      reinterpret_cast<volatile int*>(red)[0] = (int)(((v >> (8 + 6 * xcc)) & 63ull) == (unsigned long long)nslices);
+      ((__attribute__((address_space(3))) int*)(__attribute__((address_space(3))) void*)red)[0] = (int)(((v >> (8 + 6 * xcc)) & 63ull) == (unsigned long long)nslices);
     }
     __syncthreads();
-    local = reinterpret_cast<volatile int*>(red)[0] != 0;
+    local = ((__attribute__((address_space(3))) int*)(__attribute__((address_space(3))) void*)red)[0] != 0;    // (LDS address space: no flat_ instruction in these kernels -- FLAT retires out of order)
     __syncthreads();
   }
 

@@ -100,7 +100,10 @@ __device__ __forceinline__ void ns_recurrence(const PersistFwdArgs& a, const Per
       wreg[p][j] = *reinterpret_cast<const bf16x8*>(S.w_blk + ((int64_t)(tile0 + j) * KB + kb) * 512 + lane * 8);
   }
   bf16x8 wih[FUSED ? 4 : 1][2];
-  f32x4 biasv[2];
+  // (the bias of the fused layer 0 lives in LDS, in the 32 pad bytes of the gates rows of the transpose area -- entry e
+  // = (wave, tile j, lane >> 4) at row e: as registers it was 8 more than the H = 1024 instantiation has, and a spilling
+  // instantiation is not acceptable, see lstm_fwd_persist.hip)
+  char* const bias_lds = stage + 256 + (size_t)((2 * wave) * 4 + (lane >> 4)) * 288;      // + 4 * 288 for tile 1
   if constexpr (FUSED) {
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb)
@@ -110,7 +113,10 @@ __device__ __forceinline__ void ns_recurrence(const PersistFwdArgs& a, const Per
     // accumulator layout: lane holds gate rows 4 (lane >> 4) .. +3 of a tile = (i, f, g, o) of unit (lane >> 4)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
-      biasv[j] = *reinterpret_cast<const f32x4*>(S.bias + 16 * (size_t)(tile0 + j) + 4 * (lane >> 4));
+      if ((lane & 15) == 0)
+        *reinterpret_cast<f32x4*>(bias_lds + j * 4 * 288) =
+            *reinterpret_cast<const f32x4*>(S.bias + 16 * (size_t)(tile0 + j) + 4 * (lane >> 4));
+    __builtin_amdgcn_wave_barrier();         // written and read by this wave only
   }
 
   // ---- the 8 cells of this lane: rows m0 + 16 rg + (lane & 15), units u0 + 8 wave + 4 j + (lane >> 4)
@@ -121,12 +127,21 @@ __device__ __forceinline__ void ns_recurrence(const PersistFwdArgs& a, const Per
     const int r = m0 + 16 * rg + (lane & 15);
     rowc[rg] = r < B ? r : B - 1;
   }
+  // The cell state of the lane's 8 cells: registers -- except at H = 1024 (KB = 32: 256 W_hh registers), where it stays
+  // in the c rows of the transpose area between the steps (each lane reads back, before the gate math, exactly the
+  // words it wrote a step ago; nothing else writes them): the 8 registers are the difference between fitting and spilling
+  constexpr bool CLDS = KB == 32;
   float cst[4][2];
 #pragma unroll
   for (int rg = 0; rg < 4; ++rg)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
-      cst[rg][j] = t_first > 0 ? c_all[((size_t)t_first * B + rowc[rg]) * H + unit_q + 4 * j] : 0.0f;
+    for (int j = 0; j < 2; ++j) {
+      const float c0 = t_first > 0 ? c_all[((size_t)t_first * B + rowc[rg]) * H + unit_q + 4 * j] : 0.0f;
+      if constexpr (CLDS)
+        *reinterpret_cast<float*>(stage + 64 * 288 + (rg * 16 + (lane & 15)) * 144 + (8 * wave + 4 * j + (lane >> 4)) * 4) = c0;
+      else
+        cst[rg][j] = c0;
+    }
 
   // next step's input, requested a step early (behind the DMAs): plain layers the projection of the 8 cells
   // (8 x 16 B), the fused layer 0 the x fragments of all 64 rows (16 x 16 B).  Buffer loads: the block offsets are
@@ -178,7 +193,8 @@ __device__ __forceinline__ void ns_recurrence(const PersistFwdArgs& a, const Per
 #pragma unroll
     for (int rg = 0; rg < 4; ++rg)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) acc[rg][j] = FUSED ? biasv[j] : nxt[rg * 2 + j];      // plain: the sum starts from the input projection
+      for (int j = 0; j < 2; ++j)            // plain: the sum starts from the input projection; fused: from the bias
+        acc[rg][j] = FUSED ? *reinterpret_cast<const f32x4*>(bias_lds + j * 4 * 288) : nxt[rg * 2 + j];
     ns_mfma_fence();
 
     // LDS address of this lane's 16 bytes in block 0; the opaque zero is re-made every step so that the 4 KB fragment
@@ -319,10 +335,13 @@ __device__ __forceinline__ void ns_recurrence(const PersistFwdArgs& a, const Per
         for (int j = 0; j < 2; ++j) {
           const f32x4 v = acc[rg][j];
           const float gi = fast_sigmoid(v[0]), gf = fast_sigmoid(v[1]), gg = fast_tanh(v[2]), go = fast_sigmoid(v[3]);
-          const float cn = gf * cst[rg][j] + gi * gg;
-          const float hn = go * fast_tanh(cn);
-          cst[rg][j] = cn;
           const int row = rg * 16 + (lane & 15), unit = 8 * wave + 4 * j + (lane >> 4);
+          float cprev;
+          if constexpr (CLDS) cprev = *reinterpret_cast<const float*>(sc + row * 144 + unit * 4);
+          else cprev = cst[rg][j];
+          const float cn = gf * cprev + gi * gg;
+          const float hn = go * fast_tanh(cn);
+          if constexpr (!CLDS) cst[rg][j] = cn;
           *reinterpret_cast<bf16x4*>(sg + row * 288 + unit * 8) = (bf16x4){(bf16_t)gi, (bf16_t)gf, (bf16_t)gg, (bf16_t)go};
           *reinterpret_cast<float*>(sc + row * 144 + unit * 4) = cn;
           *reinterpret_cast<bf16_t*>(sh + row * 80 + unit * 2) = (bf16_t)hn;
@@ -436,10 +455,10 @@ __global__ void __launch_bounds__(256) lstm_fwd_ns_kernel(PersistFwdArgs a) {
           break;
         }
       }
-      reinterpret_cast<volatile int*>(smem)[0] = (int)(((v >> (8 + 6 * xcc)) & 63ull) == (unsigned long long)nslices);
+      ((__attribute__((address_space(3))) int*)(__attribute__((address_space(3))) void*)smem)[0] = (int)(((v >> (8 + 6 * xcc)) & 63ull) == (unsigned long long)nslices);
     }
     __syncthreads();
-    local = reinterpret_cast<volatile int*>(smem)[0] != 0;
+    local = ((__attribute__((address_space(3))) int*)(__attribute__((address_space(3))) void*)smem)[0] != 0;    // (LDS address space: no flat_ instruction in these kernels -- FLAT retires out of order)
     __syncthreads();
   }
 #ifdef CSN_PSTAMPS

@@ -181,10 +181,10 @@ __global__ void __launch_bounds__(256) lstm_fwd_persist_kernel(PersistFwdArgs a)
       const unsigned long long v = bounded_poll(a.agree + grp, a.error_flag, [&](unsigned long long x) {
         return (unsigned)(x & 0xffull) >= (unsigned)nslices;
       });
-      reinterpret_cast<volatile int*>(red)[0] = (int)(((v >> (8 + 6 * xcc)) & 63ull) == (unsigned long long)nslices);
+      ((__attribute__((address_space(3))) int*)(__attribute__((address_space(3))) void*)red)[0] = (int)(((v >> (8 + 6 * xcc)) & 63ull) == (unsigned long long)nslices);
     }
     __syncthreads();
-    local = reinterpret_cast<volatile int*>(red)[0] != 0;
+    local = ((__attribute__((address_space(3))) int*)(__attribute__((address_space(3))) void*)red)[0] != 0;    // (LDS address space: no flat_ instruction in these kernels -- FLAT retires out of order)
     __syncthreads();
   }
 
@@ -336,7 +336,13 @@ __global__ void __launch_bounds__(256) lstm_fwd_persist_kernel(PersistFwdArgs a)
       const int base = (int)((slot_in * slab + ((size_t)(m0 >> 4) * kblocks + ks_beg) * 512 + lane * 8) * 2);
       // issue order = consumption order (k-step major), pinned, so the MFMAs of k-step ks wait only for its
       // own 4 loads (counted vmcnt) while the younger ones are still in flight
-      constexpr int RING = KS > CSN_FWD_RING ? CSN_FWD_RING : KS;      // k-blocks of h in flight per wave (registers)
+      // k-blocks of h in flight per wave (registers).  NO instantiation may spill: hipcc (ROCm 7.2) spills a 4-dword
+      // fragment as 3 dwords to scratch + 1 "reload reuse" dword to an AGPR and then restores only the three -- found in
+      // the H = 512 instantiation (NQ 8, KS 4), whose W_hh fragments came back with a foreign 4th dword (0.8 % errors in
+      // h, build-dependent).  Ring depth per instantiation so that every one fits its 512 registers; `make` fails on
+      // scratch use in these kernels (tools/check_spills.py).
+      constexpr int RING_MAX = (NQ == 8 && KS == 4) ? 2 : ((NQ == 6 && KS == 6 && !DPOLL) ? 3 : CSN_FWD_RING);
+      constexpr int RING = KS > RING_MAX ? RING_MAX : KS;
       bf16x8 hf[RING][4];
       // (the rotated k-block walk as ONE running scalar offset: k-block (i + rot) % KS of the i-th group issued; as
       // per-load constants the compiler kept them in SGPRs across the steps)

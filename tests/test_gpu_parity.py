@@ -613,6 +613,24 @@ def test_cli_spampinato_trainer_surface(cuda, tmp_path):
     assert abs(loss - want) < 1e-4, (loss, want)
 
 
+def test_handoff_forms_agree_in_poisoned_workspaces(cuda):
+    """The variant-equality tests above re-run one problem in workspaces the caching allocator recycles, so a consumer
+    that loads BEFORE its producer stored finds the previous run's value of the same element -- the right bits, by
+    accident.  tools/handoff_poison.py fills the memory every run's workspace is carved from with bf16 NaNs first (data
+    to the sentinel proof, poison to the arithmetic) and requires the default, flag, no-hint and placement-independent
+    hand-offs to reproduce the clean default run bit for bit at the H = 512 (partial last M-tile), cfg2, H = 256 and cfg4
+    widths.  (This is the test that exposed the compiler's broken spill code in the H = 512 forward: DESIGN.md 3.5.)"""
+    import json
+    import subprocess
+    import sys
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "handoff_poison.py"), "2"],
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    bad = {k: v for k, v in res.items() if v["differs"] or v["nonfinite"] or v["status"]}
+    assert not bad, bad
+
+
 def test_ring_slots_never_serve_a_stale_step(cuda):
     """The hand-off by data reuses four slab addresses per layer, so a consumer must never be served the PREVIOUS occupant
     of a slot -- data, which the sentinel proof cannot tell from the right step.  The debug library `make tags`
