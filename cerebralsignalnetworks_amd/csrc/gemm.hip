@@ -92,12 +92,137 @@ gemm_generic_kernel(const T* __restrict__ A, int64_t sam, int64_t sak, const T* 
     }
 }
 
+// =====================================================================================
+// float32 GEMM on the exact f32 MFMA, 128 x 128 x 16 tiles (round 3: the exact-f32 training path spent 52 of its 108 ms
+// in the 64 x 64 generic kernel above at 61 TFLOP/s).  Both operands contiguous along K (KFAST: C = A[M,K] B[N,K]^T, the
+// projections) or along M / N (C = A[K,M]^T B[K,N], the weight gradients); 16-byte global loads, register-staged double
+// buffer, 4 waves of 64 x 64 outputs (16 accumulator tiles each), D[row = n][col = m] so that a lane's four results are
+// four consecutive columns of one row of C.  Shapes outside (M, N multiples of 128, K slices multiples of 16, 16-byte
+// aligned) stay with the generic kernel.
+// =====================================================================================
+static constexpr int kF32Pitch = 144;          // floats per LDS k-row: 128 + 16, i.e. 16 banks: the two k-rows of a ds_read_b32 half-wave never collide
+template <bool KFAST>
+__global__ void __launch_bounds__(256)
+gemm_f32_128_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ Bm, int64_t ldb,
+                    const float* __restrict__ bias, void* __restrict__ Cv, int64_t ldc, int64_t M, int64_t N, int64_t K,
+                    int out_bf16, int accumulate, int64_t k_per_split, int64_t slab_stride) {
+  __shared__ __attribute__((aligned(16))) float As[2][16][kF32Pitch];
+  __shared__ __attribute__((aligned(16))) float Bs[2][16][kF32Pitch];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int64_t m0 = (int64_t)blockIdx.y * 128, n0 = (int64_t)blockIdx.x * 128;
+  const int64_t kbeg = (int64_t)blockIdx.z * k_per_split;
+  const int64_t kend = (kbeg + k_per_split < K) ? kbeg + k_per_split : K;
+  const int nk = (int)((kend - kbeg) / 16);
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  f32x4 ra[2], rb[2];
+  auto load_tile = [&](int kt) {
+    const int64_t k0 = kbeg + (int64_t)kt * 16;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int idx = tid + i * 256;
+      if constexpr (KFAST) {
+        const int row = idx >> 2, k4 = idx & 3;
+        ra[i] = *reinterpret_cast<const f32x4*>(A + (m0 + row) * lda + k0 + 4 * k4);
+        rb[i] = *reinterpret_cast<const f32x4*>(Bm + (n0 + row) * ldb + k0 + 4 * k4);
+      } else {
+        const int kr = idx >> 5, c4 = idx & 31;
+        ra[i] = *reinterpret_cast<const f32x4*>(A + (k0 + kr) * lda + m0 + 4 * c4);
+        rb[i] = *reinterpret_cast<const f32x4*>(Bm + (k0 + kr) * ldb + n0 + 4 * c4);
+      }
+    }
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int idx = tid + i * 256;
+      if constexpr (KFAST) {
+        const int row = idx >> 2, k4 = idx & 3;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          As[buf][4 * k4 + e][row] = ra[i][e];
+          Bs[buf][4 * k4 + e][row] = rb[i][e];
+        }
+      } else {
+        const int kr = idx >> 5, c4 = idx & 31;
+        *reinterpret_cast<f32x4*>(&As[buf][kr][4 * c4]) = ra[i];
+        *reinterpret_cast<f32x4*>(&Bs[buf][kr][4 * c4]) = rb[i];
+      }
+    }
+  };
+  if (nk > 0) {
+    load_tile(0);
+    store_tile(0);
+  }
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) load_tile(kt + 1);            // in flight under this tile's MFMAs
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      float av[4], bv[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) av[i] = As[buf][kk * 4 + (lane >> 4)][wm * 64 + i * 16 + (lane & 15)];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bv[j] = Bs[buf][kk * 4 + (lane >> 4)][wn * 64 + j * 16 + (lane & 15)];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[j], av[i], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nk) store_tile(buf ^ 1);           // the other buffer: every wave left it at the barrier below, one tile ago
+    __syncthreads();
+  }
+
+  float* Cf = (float*)Cv + (int64_t)blockIdx.z * slab_stride;
+  bf16_t* Cb = (bf16_t*)Cv;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int64_t m = m0 + wm * 64 + i * 16 + (lane & 15);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t n = n0 + wn * 64 + j * 16 + (lane >> 4) * 4;
+      f32x4 v = acc[i][j];
+      if (bias) v += *reinterpret_cast<const f32x4*>(bias + n);
+      if (out_bf16) {
+        *reinterpret_cast<bf16x4*>(Cb + m * ldc + n) = (bf16x4){(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+      } else {
+        f32x4* dst = reinterpret_cast<f32x4*>(Cf + m * ldc + n);
+        *dst = accumulate ? *dst + v : v;
+      }
+    }
+  }
+}
+
 static int launch_generic(const void* A, int64_t sam, int64_t sak, const void* Bm, int64_t sbk, int64_t sbn,
                           const float* bias, void* C, int64_t ldc, int64_t M, int64_t N, int64_t K, int dtype,
                           int out_dtype, int accumulate, int splits, int64_t slab_stride, hipStream_t st) {
-  dim3 grid((unsigned)((N + 63) / 64), (unsigned)((M + 63) / 64), (unsigned)splits);
   int64_t kper = (K + splits - 1) / splits;
   kper = (kper + 15) / 16 * 16;
+  if (dtype == CSN_F32 && M % 128 == 0 && N % 128 == 0 && K % 16 == 0 && ldc % 4 == 0 &&
+      ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(Bm) | reinterpret_cast<uintptr_t>(C) |
+        reinterpret_cast<uintptr_t>(bias)) & 15) == 0 && slab_stride % 4 == 0) {
+    const dim3 g128((unsigned)(N / 128), (unsigned)(M / 128), (unsigned)splits);
+    if (sak == 1 && sbk == 1 && sam % 4 == 0 && sbn % 4 == 0) {            // both operands contiguous along K
+      gemm_f32_128_kernel<true><<<g128, 256, 0, st>>>((const float*)A, sam, (const float*)Bm, sbn, bias, C, ldc, M, N, K,
+                                                       out_dtype == CSN_BF16, accumulate, kper, slab_stride);
+      CSN_LAUNCH_CHECK();
+      return CSN_OK;
+    }
+    if (sam == 1 && sbn == 1 && sak % 4 == 0 && sbk % 4 == 0) {            // contiguous along M / N (contraction over rows)
+      gemm_f32_128_kernel<false><<<g128, 256, 0, st>>>((const float*)A, sak, (const float*)Bm, sbk, bias, C, ldc, M, N, K,
+                                                        out_dtype == CSN_BF16, accumulate, kper, slab_stride);
+      CSN_LAUNCH_CHECK();
+      return CSN_OK;
+    }
+  }
+  dim3 grid((unsigned)((N + 63) / 64), (unsigned)((M + 63) / 64), (unsigned)splits);
   if (dtype == CSN_BF16)
     gemm_generic_kernel<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)A, sam, sak, (const bf16_t*)Bm, sbk, sbn, bias, C,
                                                       ldc, M, N, K, out_dtype == CSN_BF16, accumulate, kper,
