@@ -102,7 +102,10 @@ static WsLayout make_layout(const csnLstmDesc& d, int training, const Options& o
   }
   w.x_c = take(TB * d.I * es);
   w.status = take(256);
-  // (H = 512 excluded: its 64 x 32-unit tile leaves no registers for the W_ih fragments)
+  // (H = 512 excluded: its 64 x 32-unit tile leaves no registers for the W_ih fragments.  N-split kernel: fused up to
+  // H = 768 only -- at H = 1024 W_hh alone fills the 256 AGPRs the stationary operands must live in, and with the 32
+  // registers of W_ih on top the fused instantiation computes wrong row groups (tried in round 3 once it no longer
+  // spilled: copies of one segment in different row groups differ); cfg4 keeps its layer-0 projection as a GEMM)
   w.fuse_x = w.persist && !opt.no_fuse_x &&
              (w.fwd_ns ? (d.I == 128 && d.H <= 768) : (d.I % 32 == 0 && d.I <= 128 && d.H != 512));
   if (w.fuse_x) {

@@ -558,7 +558,9 @@ int launch_fwd_ns(const PersistFwdArgs& a, hipStream_t st) {
     CSN_NS_CASE(8);
     CSN_NS_CASE(12);
     CSN_NS_CASE(16);
-    CSN_NS_CASE(32);
+    case 1024:      // (no fused instantiation at H = 1024: see the plan's fuse_x in lstm.hip)
+      CSN_REQUIRE(!fused, "launch_fwd_ns: the fused layer-0 projection exists up to H = 768");
+      return launch_ns_t<32, false, false>(a, st);
   }
 #undef CSN_NS_CASE
   return fail(CSN_ERR_UNSUPPORTED, "launch_fwd_ns: no kernel for H=%d", a.H);
