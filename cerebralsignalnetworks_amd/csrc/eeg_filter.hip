@@ -264,7 +264,10 @@ __global__ void __launch_bounds__(512, 4) eeg_filter_scan_kernel(const ScanArgs<
       g[j] = idx < 4 * q4 ? got : (f32x4){0.f, 0.f, 0.f, 0.f};
     }
   };
-  request(blockIdx.x);
+  // the next tile's loads stay in flight across a tile only where the 32 registers fit (3 sections: the reference's
+  // training filter); the other section counts load at the top of each tile -- no instantiation may spill
+  constexpr bool PREFETCH = NSEC >= 1 && NSEC <= 3;
+  if constexpr (PREFETCH) request(blockIdx.x);
   // store phase: this thread writes channel quad q of time steps (tid >> 3) + 64 it
   const int sq = tid & 7, st0 = tid >> 3;
   const int64_t tstride = time_major ? (int64_t)B * C : (int64_t)C;
@@ -280,10 +283,13 @@ __global__ void __launch_bounds__(512, 4) eeg_filter_scan_kernel(const ScanArgs<
     // ---- 1b: through the wave's own part of LDS (no workgroup barrier: written and read by this wave only) into this
     // thread's 32 samples (float32 between the phases: 32 registers; every phase computes in float64)
     float v[kScanLen];
+    if constexpr (!PREFETCH) request(tl);
 #pragma unroll
     for (int j = 0; j < 8; ++j) *reinterpret_cast<f32x4*>(__builtin_assume_aligned(tile + sa[j], 16)) = g[j];
     __builtin_amdgcn_sched_barrier(0);
-    if (tl + (int)gridDim.x < ntiles) request(tl + gridDim.x);
+    if constexpr (PREFETCH) {
+      if (tl + (int)gridDim.x < ntiles) request(tl + gridDim.x);
+    }
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_wave_barrier();
     {
