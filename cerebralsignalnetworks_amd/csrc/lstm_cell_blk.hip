@@ -305,20 +305,27 @@ __global__ void __launch_bounds__(256) lstm_cell_fwd_il_kernel(CellFwdArgs a) {
   const int kblocks = H >> 5;
   CSN_STAMP(0);
 
-  // epilogue operands, requested first: pair p -> row m0 + p / NQ, units u0 + 4 (p % NQ) .. + 3
+  // epilogue operands: pair p -> row m0 + p / NQ, units u0 + 4 (p % NQ) .. + 3.  Requested FIRST (in flight under the
+  // whole contraction) where the registers allow it; with 8 unit quads per workgroup (H = 128, 256, 512, 1024) the 40
+  // registers are what made the kernel spill 74 -- and this compiler's spill code is not trusted: there
+  // they are requested behind the contraction.
+  constexpr bool EPI_EARLY = NQ < 8;
   float4 xp[NPASS][4], cp[NPASS];
+  auto request_epilogue = [&]() {
 #pragma unroll
-  for (int ps = 0; ps < NPASS; ++ps) {
-    const int p = tid + ps * 256;
-    const int row = m0 + p / NQ, uq = u0 + 4 * (p % NQ);
-    cp[ps] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (p < NPAIR && row < B) {
-      const float4* xr = reinterpret_cast<const float4*>(P.xproj + (int64_t)row * 4 * H + 4 * (int64_t)uq);
+    for (int ps = 0; ps < NPASS; ++ps) {
+      const int p = tid + ps * 256;
+      const int row = m0 + p / NQ, uq = u0 + 4 * (p % NQ);
+      cp[ps] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (p < NPAIR && row < B) {
+        const float4* xr = reinterpret_cast<const float4*>(P.xproj + (int64_t)row * 4 * H + 4 * (int64_t)uq);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) xp[ps][q] = nt_load(xr + q);
-      if (P.c_prev != nullptr) cp[ps] = *reinterpret_cast<const float4*>(P.c_prev + (int64_t)row * H + uq);
+        for (int q = 0; q < 4; ++q) xp[ps][q] = nt_load(xr + q);
+        if (P.c_prev != nullptr) cp[ps] = *reinterpret_cast<const float4*>(P.c_prev + (int64_t)row * H + uq);
+      }
     }
-  }
+  };
+  if constexpr (EPI_EARLY) request_epilogue();
 
   f32x4 acc[4][NQ];
 #pragma unroll
@@ -377,6 +384,7 @@ __global__ void __launch_bounds__(256) lstm_cell_fwd_il_kernel(CellFwdArgs a) {
 #pragma unroll
     for (int j = 0; j < NQ; ++j)
       red[(wave * NT + rg * NQ + j) * 65 + lane] = make_float4(acc[rg][j][0], acc[rg][j][1], acc[rg][j][2], acc[rg][j][3]);
+  if constexpr (!EPI_EARLY) request_epilogue();
   __syncthreads();
   CSN_STAMP(2);
 
@@ -589,10 +597,10 @@ int launch_cell_fwd_il(const CellFwdArgs& a, int nprob, hipStream_t st, int max_
   const int steps = H / 128;                       // k-steps per wave
   const int nk = pick_nk(steps, max_nk);
   const int nq = (H % 24 == 0) ? 6 : ((H % 32 == 0) ? 8 : 4);
-#define CSN_CASE(NQ, NK) if (nq == NQ && nk == NK) return launch_fwd_t<NQ, NK>(a, nprob, st)
-  CSN_CASE(6, 3); CSN_CASE(6, 2); CSN_CASE(6, 1);
-  CSN_CASE(8, 2); CSN_CASE(8, 1);
-  CSN_CASE(4, 3); CSN_CASE(4, 2); CSN_CASE(4, 1);
+#define CSN_CASE(NQ, NK) if (nq == NQ) return launch_fwd_t<NQ, NK>(a, nprob, st)
+  // (k-blocks per pass: only 1 is built -- the deeper passes CSN_FWD_NK used to select spilled 32 - 147 registers)
+  (void)nk;
+  CSN_CASE(6, 1); CSN_CASE(8, 1); CSN_CASE(4, 1);
 #undef CSN_CASE
   if (nq == 8) return launch_fwd_t<8, 1>(a, nprob, st);
   return fail(CSN_ERR_UNSUPPORTED, "launch_cell_fwd_il: no kernel for H=%d", H);
