@@ -44,7 +44,12 @@ def test_filter_znorm_matches_golden(cuda, golden, order, ddof):
     np.testing.assert_allclose(y, want, rtol=0, atol=2e-6)
 
 
-@pytest.mark.parametrize("B,C,T", [(3, 128, 500), (2, 96, 460), (1, 5, 461), (2, 128, 440), (1, 1, 2)])
+@pytest.mark.parametrize("B,C,T", [(3, 128, 500), (2, 96, 460), (1, 5, 461), (2, 128, 440), (1, 1, 2),
+                                   # scan kernel edges: last tile / last wave partly empty (60 rows), T = 512 (no leading zeros),
+                                   # T = 36 (14 of 16 chunk lanes all zeros), one float4 per row, 33 rows (second tile = 1 row)
+                                   (3, 20, 512), (5, 12, 36), (2, 8, 8), (1, 132, 260),
+                                   # row-walking fallback: T > 512, T % 4 != 0 with C % 4 == 0
+                                   (2, 8, 600), (2, 8, 130)])
 def test_filter_shapes_layouts_dtypes(cuda, B, C, T):
     x = eeg_filter.synthetic_eeg(B, C, T, seed=B * 1000 + T)
     sos = eeg_filter.design_bandpass_sos(1000, 3)
@@ -199,7 +204,9 @@ def _sig(x):
     return 1 / (1 + np.exp(-x))
 
 
-@pytest.mark.parametrize("B,H", [(4, 64), (70, 96), (256, 768)])
+@pytest.mark.parametrize("B,H", [(4, 64), (70, 96), (256, 768),
+                                 # K-split cell kernels (H % 128 == 0 in f32, % 256 in bf16) with ragged row tiles
+                                 (70, 256), (33, 1024), (130, 512)])
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 def test_cell_forward_backward_step(cuda, B, H, dt):
     rng = np.random.default_rng(B + H)
