@@ -70,6 +70,7 @@ static constexpr int kRedTile = 71;
 static constexpr unsigned long long kSpinTimeoutTicks = 20000000ull;   // 0.2 s of the 100 MHz wall clock
 
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
 
 __device__ __forceinline__ bf16x8 load_sc1_b128(__amdgpu_buffer_rsrc_t rsrc, int byte_off, int soff = 0) {
   // aux = 16: sc1 (agent-coherent, bypasses this CU's L1; MI355X_MICROARCH.md visibility table)
@@ -126,6 +127,13 @@ __global__ void __launch_bounds__(256) lstm_fwd_persist_kernel(PersistFwdArgs a)
   constexpr int NT = 4 * NQ;
   constexpr int NPAIR = 64 * NQ;
   constexpr int NPASS = (NPAIR + 255) / 256;
+  // The epilogue's work items are (row, unit-quad) pairs, one per thread and pass.  At NQ = 6 there are 384 of them: a full
+  // pass and 128 left over -- as a second pass of whole pairs those kept waves 0 and 1 busy for a full pass while waves 2
+  // and 3 waited at the barrier (an ablation without them: 212 -> 185 us per launch).  HALFQ: the 128 quads of that last
+  // pass are split into unit PAIRS over all 256 threads (thread t: quad 256 NFULL + t / 2, units 2 (t & 1), +1), so every
+  // wave runs half a pass; the two lanes of a quad meet through a DPP swap for the one 8-byte hand-off piece.
+  constexpr bool HALFQ = (NPAIR % 256) == 128;
+  constexpr int NFULL = NPAIR / 256;
   extern __shared__ __attribute__((aligned(16))) float4 red[];   // [4][NT][kRedTile], then [NQ][4] bias
   const int B = a.B, H = a.H, MT = a.MT;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -227,17 +235,26 @@ __global__ void __launch_bounds__(256) lstm_fwd_persist_kernel(PersistFwdArgs a)
   float4 cst[NPASS];
   int prow[NPASS], puq[NPASS], prl[NPASS], pj[NPASS];
   bool pok[NPASS];
+  const int hq = tid & 1;                       // split pass: which unit pair of the quad
 #pragma unroll
   for (int ps = 0; ps < NPASS; ++ps) {
-    const int p = tid + ps * 256;
+    const bool hp = HALFQ && ps == NFULL;
+    const int p = hp ? NFULL * 256 + (tid >> 1) : tid + ps * 256;
     prl[ps] = p / NQ;
     pj[ps] = p % NQ;
     prow[ps] = m0 + prl[ps];
-    puq[ps] = u0 + 4 * pj[ps];
+    puq[ps] = u0 + 4 * pj[ps];                  // (the quad's first unit, also in the split pass)
     pok[ps] = p < NPAIR && prow[ps] < B;
     cst[ps] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (pok[ps] && t_first > 0)
-      cst[ps] = *reinterpret_cast<const float4*>(c_all + ((size_t)t_first * B + prow[ps]) * H + puq[ps]);
+    if (pok[ps] && t_first > 0) {
+      const float* cp = c_all + ((size_t)t_first * B + prow[ps]) * H + puq[ps];
+      if (hp) {
+        const f32x2 c2 = *reinterpret_cast<const f32x2*>(cp + 2 * hq);
+        cst[ps] = make_float4(c2[0], c2[1], 0.f, 0.f);
+      } else {
+        cst[ps] = *reinterpret_cast<const float4*>(cp);
+      }
+    }
   }
 
   const __amdgpu_buffer_rsrc_t hsrc =
@@ -260,8 +277,13 @@ __global__ void __launch_bounds__(256) lstm_fwd_persist_kernel(PersistFwdArgs a)
     for (int ps = 0; ps < NPASS; ++ps)
       if (pok[ps]) {
         const f32x4* xr = reinterpret_cast<const f32x4*>(xproj + ((size_t)t * B + prow[ps]) * 4 * H + 4 * (size_t)puq[ps]);
+        if (HALFQ && ps == NFULL) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) nxt[ps * 4 + q] = nt_load(xr + q);
+          for (int q = 0; q < 2; ++q) nxt[ps * 4 + q] = nt_load(xr + 2 * hq + q);
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) nxt[ps * 4 + q] = nt_load(xr + q);
+        }
       }
   };
   request_input(t_first);
@@ -315,6 +337,7 @@ __global__ void __launch_bounds__(256) lstm_fwd_persist_kernel(PersistFwdArgs a)
 #pragma unroll
           for (int ps = 1; ps < NPASS; ++ps)
             if (64 * pw + 63 + ps * 256 < NPAIR) pp = 64 * pw + 63 + ps * 256;
+          if (HALFQ) pp = NFULL * 256 + 32 * pw + 31;     // split pass: the quad of the wave's last even lane (thread 64 pw + 62)
           fl = reinterpret_cast<const unsigned*>(h_blk_all + slot_in * slab +
                                                  blk_offset(m0 + pp / NQ, (wave * npw + pi) * 4 * NQ + 4 * (pp % NQ), H));
         } else {
@@ -447,7 +470,7 @@ __global__ void __launch_bounds__(256) lstm_fwd_persist_kernel(PersistFwdArgs a)
     if (dpoll && !CSN_DPOLL_NO_REARM(a.data_polls)) {
 #pragma unroll
       for (int ps = 0; ps < NPASS; ++ps) {
-        if (tid + ps * 256 >= NPAIR) continue;      // (rows beyond B are padding rows of the slab: re-armed like the rest)
+        if (HALFQ && ps == NFULL ? hq != 0 : tid + ps * 256 >= NPAIR) continue;      // (rows beyond B are padding rows of the slab: re-armed like the rest; split pass: one lane per quad)
         unsigned long long* sp = reinterpret_cast<unsigned long long*>(
             h_blk_all + (size_t)((t + 3) & 3) * slab + blk_offset(prow[ps], puq[ps], H));
         if (local) *sp = ~0ull;
@@ -462,7 +485,7 @@ __global__ void __launch_bounds__(256) lstm_fwd_persist_kernel(PersistFwdArgs a)
       if (!pok[ps]) {
         // padding rows of the last M-tile: nobody computes them, but with data polls their pieces must stop being
         // the sentinel (zeros: the rows feed only their own, never stored, outputs)
-        if (dpoll && tid + ps * 256 < NPAIR) {
+        if (dpoll && (HALFQ && ps == NFULL ? hq == 0 : tid + ps * 256 < NPAIR)) {
           unsigned long long* zp = reinterpret_cast<unsigned long long*>(h_blk_all + slot_out * slab + blk_offset(prow[ps], puq[ps], H));
 #ifdef CSN_SLAB_TAGS
           const unsigned long long zv = (unsigned long long)((t >> 2) & 1);
@@ -474,12 +497,16 @@ __global__ void __launch_bounds__(256) lstm_fwd_persist_kernel(PersistFwdArgs a)
         }
         continue;
       }
+      const bool hp = HALFQ && ps == NFULL;           // (a constant once the pass loop is unrolled)
+      const int nq = hp ? 2 : 4;                         // units this thread finishes in this pass
+      const int q0 = hp ? 2 * hq : 0;                    // first of them inside the quad
       const int rl = prl[ps], j = pj[ps], row = prow[ps], uq = puq[ps];
       float gi[4], gf[4], gg[4], go[4], cn[4], hn[4];
       const float cpv[4] = {cst[ps].x, cst[ps].y, cst[ps].z, cst[ps].w};
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const int idx = ((rl >> 4) * NQ + j) * kRedTile + (rl & 15) + 16 * q;
+        if (q >= nq) continue;
+        const int idx = ((rl >> 4) * NQ + j) * kRedTile + (rl & 15) + 16 * (q0 + q);
         float4 sum = red[idx];
 #pragma unroll
         for (int w2 = 1; w2 < 4; ++w2) {
@@ -494,22 +521,46 @@ __global__ void __launch_bounds__(256) lstm_fwd_persist_kernel(PersistFwdArgs a)
         cn[q] = gf[q] * cpv[q] + gi[q] * gg[q];
         hn[q] = go[q] * fast_tanh(cn[q]);
       }
-      cst[ps] = make_float4(cn[0], cn[1], cn[2], cn[3]);
-      // the hand-off payload first: plain stores stay in this XCD's L2 (L2-local groups), write-through otherwise
       bf16_t* hdst = h_blk_all + slot_out * slab + blk_offset(row, uq, H);
-      if (local) store_plain_b64(hdst, hn, t >> 2);
-      else store_wt_b64(hdst, hn, t >> 2);
-      if (gates != nullptr) {
-        bf16x8 lo = {(bf16_t)gi[0], (bf16_t)gf[0], (bf16_t)gg[0], (bf16_t)go[0], (bf16_t)gi[1], (bf16_t)gf[1], (bf16_t)gg[1], (bf16_t)go[1]};
-        bf16x8 hi = {(bf16_t)gi[2], (bf16_t)gf[2], (bf16_t)gg[2], (bf16_t)go[2], (bf16_t)gi[3], (bf16_t)gf[3], (bf16_t)gg[3], (bf16_t)go[3]};
-        bf16x8* gp = reinterpret_cast<bf16x8*>(gates + ((size_t)t * B + row) * 4 * H + 4 * (size_t)uq);
-        __builtin_nontemporal_store(lo, gp);
-        __builtin_nontemporal_store(hi, gp + 1);
+      if (hp) {
+        cst[ps] = make_float4(cn[0], cn[1], 0.f, 0.f);
+        // the quad's 8-byte hand-off piece: the even lane collects its neighbour's two values (quad_perm [1,0,3,2]) and
+        // stores -- one store per piece, as in the full passes (the consumers' proof is per 8-byte piece)
+        union { bf16_t b[2]; unsigned u; } pk;
+        pk.b[0] = (bf16_t)hn[0];
+        pk.b[1] = (bf16_t)hn[1];
+        const unsigned other = (unsigned)__builtin_amdgcn_update_dpp(0, (int)pk.u, 0xB1, 0xf, 0xf, false);
+        if (hq == 0) {
+          unsigned long long piece = (unsigned long long)pk.u | ((unsigned long long)other << 32);
+#ifdef CSN_SLAB_TAGS
+          piece = (piece & ~1ull) | (unsigned long long)((t >> 2) & 1);
+#endif
+          if (local) *reinterpret_cast<unsigned long long*>(hdst) = piece;
+          else __hip_atomic_store(reinterpret_cast<unsigned long long*>(hdst), piece, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (gates != nullptr) {
+          bf16x8 lo = {(bf16_t)gi[0], (bf16_t)gf[0], (bf16_t)gg[0], (bf16_t)go[0], (bf16_t)gi[1], (bf16_t)gf[1], (bf16_t)gg[1], (bf16_t)go[1]};
+          __builtin_nontemporal_store(lo, reinterpret_cast<bf16x8*>(gates + ((size_t)t * B + row) * 4 * H + 4 * (size_t)(uq + q0)));
+        }
+        __builtin_nontemporal_store((f32x2){cn[0], cn[1]}, reinterpret_cast<f32x2*>(c_all + ((size_t)(t + 1) * B + row) * H + uq + q0));
+        __builtin_nontemporal_store(pk.u, reinterpret_cast<unsigned*>(h_all + ((size_t)(t + 1) * B + row) * H + uq + q0));
+      } else {
+        cst[ps] = make_float4(cn[0], cn[1], cn[2], cn[3]);
+        // the hand-off payload first: plain stores stay in this XCD's L2 (L2-local groups), write-through otherwise
+        if (local) store_plain_b64(hdst, hn, t >> 2);
+        else store_wt_b64(hdst, hn, t >> 2);
+        if (gates != nullptr) {
+          bf16x8 lo = {(bf16_t)gi[0], (bf16_t)gf[0], (bf16_t)gg[0], (bf16_t)go[0], (bf16_t)gi[1], (bf16_t)gf[1], (bf16_t)gg[1], (bf16_t)go[1]};
+          bf16x8 hi = {(bf16_t)gi[2], (bf16_t)gf[2], (bf16_t)gg[2], (bf16_t)go[2], (bf16_t)gi[3], (bf16_t)gf[3], (bf16_t)gg[3], (bf16_t)go[3]};
+          bf16x8* gp = reinterpret_cast<bf16x8*>(gates + ((size_t)t * B + row) * 4 * H + 4 * (size_t)uq);
+          __builtin_nontemporal_store(lo, gp);
+          __builtin_nontemporal_store(hi, gp + 1);
+        }
+        __builtin_nontemporal_store((f32x4){cn[0], cn[1], cn[2], cn[3]},
+                                    reinterpret_cast<f32x4*>(c_all + ((size_t)(t + 1) * B + row) * H + uq));
+        __builtin_nontemporal_store((bf16x4){(bf16_t)hn[0], (bf16_t)hn[1], (bf16_t)hn[2], (bf16_t)hn[3]},
+                                    reinterpret_cast<bf16x4*>(h_all + ((size_t)(t + 1) * B + row) * H + uq));
       }
-      __builtin_nontemporal_store((f32x4){cn[0], cn[1], cn[2], cn[3]},
-                                  reinterpret_cast<f32x4*>(c_all + ((size_t)(t + 1) * B + row) * H + uq));
-      __builtin_nontemporal_store((bf16x4){(bf16_t)hn[0], (bf16_t)hn[1], (bf16_t)hn[2], (bf16_t)hn[3]},
-                                  reinterpret_cast<bf16x4*>(h_all + ((size_t)(t + 1) * B + row) * H + uq));
     }
     CSN_PSTAMP(3);     // epilogue (LDS reads, math, store issue)
     // publish: every storing wave drains, workgroup barrier (also frees `red`), one lane signals.
