@@ -46,7 +46,7 @@
 #define CSN_STAMP_BLOCK 11     // group 3 (layer 0 at cfg2), slice 1; 15 = group 7 (layer 1)
 #endif
 // diagnostic build only (tools/persist_bench.hip): per-phase wall-clock sums of workgroup (0,0)
-__device__ unsigned long long g_pstamps[8];
+__device__ unsigned long long g_pstamps[16];
 #define CSN_PSTAMP(i)                                                          \
   do {                                                                         \
     __builtin_amdgcn_sched_barrier(0);                                         \
@@ -521,6 +521,9 @@ __global__ void __launch_bounds__(256) lstm_fwd_persist_kernel(PersistFwdArgs a)
         cn[q] = gf[q] * cpv[q] + gi[q] * gg[q];
         hn[q] = go[q] * fast_tanh(cn[q]);
       }
+#ifdef CSN_PSTAMPS
+      if (ps == 0) CSN_PSTAMP(8);      // (diagnostic: pass 0 LDS reads + gate math)
+#endif
       bf16_t* hdst = h_blk_all + slot_out * slab + blk_offset(row, uq, H);
       if (hp) {
         cst[ps] = make_float4(cn[0], cn[1], 0.f, 0.f);
@@ -561,6 +564,9 @@ __global__ void __launch_bounds__(256) lstm_fwd_persist_kernel(PersistFwdArgs a)
         __builtin_nontemporal_store((bf16x4){(bf16_t)hn[0], (bf16_t)hn[1], (bf16_t)hn[2], (bf16_t)hn[3]},
                                     reinterpret_cast<bf16x4*>(h_all + ((size_t)(t + 1) * B + row) * H + uq));
       }
+#ifdef CSN_PSTAMPS
+      if (ps == 0) CSN_PSTAMP(9);      // (diagnostic: pass 0 store issue)
+#endif
     }
     CSN_PSTAMP(3);     // epilogue (LDS reads, math, store issue)
     // publish: every storing wave drains, workgroup barrier (also frees `red`), one lane signals.
@@ -636,7 +642,7 @@ int launch_fwd_persist(const PersistFwdArgs& a, hipStream_t st) {
 #ifdef CSN_PSTAMPS
 // diagnostic build only (make diag): read and clear the per-phase tick sums
 extern "C" int csn_debug_read_pstamps(unsigned long long* out) {
-  unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long z[16] = {0};
   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pstamps), sizeof(z)) != hipSuccess) return 1;
   if (hipMemcpyToSymbol(HIP_SYMBOL(g_pstamps), z, sizeof(z)) != hipSuccess) return 1;
   return 0;

@@ -16,14 +16,17 @@ lib = cabi.load()
 lib.csn_debug_read_pstamps.argtypes = [ctypes.POINTER(ctypes.c_ulonglong)]
 lib.csn_debug_read_bstamps.argtypes = [ctypes.POINTER(ctypes.c_ulonglong)]
 lib.csn_debug_read_nstamps.argtypes = [ctypes.POINTER(ctypes.c_ulonglong)]
-lib.csn_debug_read_wstamps.argtypes = [ctypes.POINTER(ctypes.c_ulonglong)]
+has_ws = hasattr(lib, "csn_debug_read_wstamps")      # (wave-specialised forward: experiments library only)
+if has_ws:
+    lib.csn_debug_read_wstamps.argtypes = [ctypes.POINTER(ctypes.c_ulonglong)]
 buf = (ctypes.c_ulonglong * 16)()
 for it in range(4):
     tr.train_step(x, tg)
     torch.cuda.synchronize()
     # the stamping workgroup (blockIdx.x == 11) belongs to ONE layer's group: sums are over that layer's T steps
-    lib.csn_debug_read_wstamps(buf)
-    if sum(buf) != 0:
+    if has_ws:
+        lib.csn_debug_read_wstamps(buf)
+    if has_ws and sum(buf) != 0:
         w = [buf[i] * 0.01 / T for i in range(16)]
         print("step %d fwd-ws per-step us, MFMA wave 0 (4 chains): wait ready %.2f | lds reads + mfma %.2f | tiles to lds + bump %.2f | sum %.2f"
               % (it, w[0], w[1], w[2], sum(w[:3])))
@@ -41,5 +44,7 @@ for it in range(4):
         if name == "fwd-nsplit":
             print("   nsplit detail per-step us: dma issue %.2f | x-mfma + input request %.2f | wait g0 %.2f | g0 mfma + wait g1 %.2f | g1,g2 mfma + waits %.2f | (g3 mfma in loads+mfma rest)"
                   % tuple(buf[i] * 0.01 / T for i in (8, 9, 10, 11, 12)))
+        if name == "fwd-ksplit":
+            print("   fwd epilogue detail per-step us: pass 0 reads + math %.2f | pass 0 store issue %.2f | (rest of 'epilogue' = the split pass)" % (buf[8] * 0.01 / T, buf[9] * 0.01 / T))
         print("step %d %s per-step us: wait %.2f | loads+mfma %.2f | lds/gate-math %.2f | epilogue %.2f | drain %.2f | signal %.2f | sum %.2f | prologue per launch %.1f us"
               % (it, name, *per, sum(per), buf[6] * 0.01 / 16), flush=True)
