@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("CSN_LIB_PATH") or os.path.join(_HERE, "lib", "libcsn_
 
 CSN_F32, CSN_BF16 = 0, 1
 STATUS_TIMEOUT, STATUS_NONFINITE, STATUS_STALE_SLOT = 1, 2, 4      # bits of csn_lstm_status_read (include/csn_hip.h)
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _c_void_p, _c_int, _c_i64, _c_size_t, _c_float = (ctypes.c_void_p, ctypes.c_int, ctypes.c_int64,
                                                   ctypes.c_size_t, ctypes.c_float)
@@ -40,6 +40,7 @@ SIGNATURES = {
     "csn_lstm_plan_destroy": (None, [_c_void_p]),
     "csn_lstm_plan_workspace_bytes": (_c_size_t, [_c_void_p]),
     "csn_lstm_plan_path": (_c_int, [_c_void_p]),
+    "csn_lstm_plan_dgates_copies": (_c_int, [_c_void_p]),
     "csn_lstm_workspace_bytes": (_c_size_t, [ctypes.POINTER(LstmDesc), _c_int]),
     "csn_lstm_forward": (_c_int, [_c_void_p, _c_void_p, _c_i64, _c_i64,
                                   ctypes.POINTER(_c_void_p), ctypes.POINTER(_c_void_p),
@@ -254,6 +255,10 @@ class LstmPlan:
     def path(self):
         """0 generic cells, 1 per-diagonal bf16 launches, 2 weight-stationary forward, 3 + weight-stationary backward."""
         return load().csn_lstm_plan_path(self._plan)
+
+    def dgates_copies(self):
+        """Copies of the gate gradients the last backward wrote per step (csn_hip.h): 1, 2, or 0 before any backward."""
+        return load().csn_lstm_plan_dgates_copies(self._plan)
 
     def forward(self, x_bti, w_ih, w_hh, b_ih, b_hh, want_all=False):
         d = self.desc

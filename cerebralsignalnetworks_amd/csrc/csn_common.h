@@ -48,7 +48,7 @@ int fail(int status, const char* fmt, ...);
 // library keeps no mutable global state, so plans on different streams / threads / devices never share any.
 struct Options {
   bool cell_v1, no_persist, no_persist_bwd, persist_streams, no_xcd_local, no_rotate, no_fuse_x, no_beside,
-      no_side_stream, gemm_slot, fwd_ksplit, fwd_nsplit, fwd_halves, fwd_ws, fwd_flags, bwd_flags, dpoll_no_hint, fwd_hint, beside_fwd, xproj_bf16, wgrad_overlap, gemm_no_dma, gemm_no_256, gemm_generic, gemm_lds64, tn_no_tr, tn_no_stagger, filter_v1, tags_no_rearm;
+      no_side_stream, gemm_slot, fwd_ksplit, fwd_nsplit, fwd_halves, fwd_ws, fwd_flags, bwd_flags, dpoll_no_hint, fwd_hint, beside_fwd, xproj_bf16, wgrad_overlap, gemm_no_dma, gemm_no_256, gemm_generic, gemm_lds64, tn_no_tr, tn_no_stagger, filter_v1, tags_no_rearm, bwd_single_copy;
   int chunk;       // timesteps per weight-stationary launch
   int tn_stages;   // LDS-DMA ring depth of the 256 x 256 weight-gradient kernel
   int fwd_nk;
@@ -78,6 +78,7 @@ static inline Options options_from_env() {
   o.beside_fwd = on("CSN_BESIDE_FWD");
   o.xproj_bf16 = on("CSN_XPROJ_BF16");
   o.wgrad_overlap = on("CSN_WGRAD_OVERLAP");
+  o.bwd_single_copy = on("CSN_BWD_SINGLE_COPY");
 #endif
   o.fwd_flags = on("CSN_FWD_FLAGS");
   o.bwd_flags = on("CSN_BWD_FLAGS");
@@ -153,7 +154,9 @@ int launch_colsum_partial(const void* X, int64_t R, int64_t N, int dtype, void* 
 int launch_gemm_nt_beside(const void* A, const void* Bt, const float* bias, float* C, int64_t M, int64_t N, int64_t K,
                           int max_wgs, hipStream_t st);
 int launch_gemm_tn_slabs(const void* A, const void* B, float* slabs, int64_t M, int64_t N, int64_t K, int dtype,
-                         hipStream_t st, int* S_out, float* colsum, int* colsum_done, const Options& opt);
+                         hipStream_t st, int* S_out, float* colsum, int* colsum_done, const Options& opt, int a_blocked = 0);
+// may A[K, M] of that call be handed over in the fragment-major block layout of the recurrence (blk_offset)?
+bool gemm_tn_takes_blocked_a(int64_t M, int64_t N, int64_t K, const Options& opt);
 // C[M,N] (+)= A[M,K] Bt[N,K]^T (+ bias): the body of csn_gemm_nt with the switches passed in
 int gemm_nt(const void* A, const void* Bt, const float* bias, void* C, int64_t M, int64_t N, int64_t K, int dtype,
             int out_dtype, int accumulate, hipStream_t st, const Options& opt);

@@ -14,6 +14,7 @@
 //                    ds_read_b64_tr_b16; split-K over blockIdx.z into float32 slabs that a
 //                    fixed-order reduction combines (bitwise reproducible, no atomics).
 #include "csn_common.h"
+#include "lstm_cell_common.h"
 
 namespace csn {
 
@@ -817,7 +818,7 @@ __device__ __forceinline__ bf16x8 tr_read_pair(unsigned addr) {
 template <int NSTAGE, bool COLSUM, bool STAGGER = false>
 __global__ void __launch_bounds__(512)
 gemm_tn_256_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ Bm, float* __restrict__ slabs,
-                   int64_t M, int64_t N, int64_t K, int64_t k_per_split, float* __restrict__ colsum) {
+                   int64_t M, int64_t N, int64_t K, int64_t k_per_split, float* __restrict__ colsum, int a_blocked) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];  // NSTAGE x (A 16 KB + B 16 KB)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 2, wn = wave & 3;
@@ -842,7 +843,9 @@ gemm_tn_256_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ Bm, 
     int64_t am = m0 + col, bn = n0 + col;
     am = am + 8 <= M ? am : M - 8;
     bn = bn + 8 <= N ? bn : N - 8;
-    a_src[i] = A + (kbeg + kr) * M + am;
+    // (a_blocked: A[K, M] in the recurrence's fragment-major 16 x 32 blocks, blk_offset -- the same 16-byte pieces at other
+    // addresses; 32 more k-rows are two row blocks = 32 M elements further, like in the row-major layout)
+    a_src[i] = a_blocked ? A + blk_offset(kbeg + kr, am, M) : A + (kbeg + kr) * M + am;
     b_src[i] = Bm + (kbeg + kr) * N + bn;
   }
   auto issue = [&](int h) {
@@ -1035,7 +1038,9 @@ static int tn_splits(int64_t M, int64_t N, int64_t K) {
 }
 // the 256 x 256 kernel: one workgroup per CU (128 KB of LDS), so the K splits fill the 256 CUs once
 static bool tn_use_256(int64_t M, int64_t N, int64_t K, const Options& opt) {
-  return M >= 256 && N >= 256 && K % 64 == 0 && K >= 8192 && !opt.gemm_no_dma && !opt.gemm_no_256;
+  // (N >= 128: at N = 128 -- the layer-0 input weight gradient -- half of every tile's columns are clamped duplicates
+  // whose results are discarded, and it still beats the 128 x 128 register-staged kernel)
+  return M >= 256 && N >= 128 && K % 64 == 0 && K >= 8192 && !opt.gemm_no_dma && !opt.gemm_no_256;
 }
 static int tn_splits_256(int64_t M, int64_t N, int64_t K) {
   const int64_t tiles = ((M + 255) / 256) * ((N + 255) / 256);
@@ -1144,9 +1149,14 @@ extern "C" size_t csn_gemm_tn_scratch_bytes(int64_t M, int64_t N, int64_t K) {
 namespace csn {
 // colsum (optional): device buffer of at least 64 * M floats; if the kernel that runs can produce the column sums
 // of A on the way (one partial row of M values per K split), *colsum_done is set to 1.
+bool gemm_tn_takes_blocked_a(int64_t M, int64_t N, int64_t K, const Options& opt) {
+  return (M % 32 == 0) && (N % 8 == 0) && (K % 16 == 0) && tn_use_256(M, N, K, opt);
+}
 int launch_gemm_tn_slabs(const void* A, const void* B, float* slabs, int64_t M, int64_t N, int64_t K, int dtype,
-                         hipStream_t st, int* S_out, float* colsum, int* colsum_done, const Options& opt) {
+                         hipStream_t st, int* S_out, float* colsum, int* colsum_done, const Options& opt, int a_blocked) {
   if (colsum_done) *colsum_done = 0;
+  CSN_REQUIRE(!a_blocked || (dtype == CSN_BF16 && gemm_tn_takes_blocked_a(M, N, K, opt)),
+              "launch_gemm_tn_slabs: a fragment-major A needs the 256 x 256 kernel");
   const bool aligned16 = ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15) == 0;
   if (dtype == CSN_BF16 && (M % 8 == 0) && (N % 8 == 0) && aligned16 && tn_use_256(M, N, K, opt)) {
     const int S2 = tn_splits_256(M, N, K);
@@ -1164,12 +1174,12 @@ int launch_gemm_tn_slabs(const void* A, const void* B, float* slabs, int64_t M, 
     if (!opt.tn_no_stagger && nst == 4) {      // (the default; CSN_TN_STAGES selects one of the single-phase rings)
       if (int rc = ensure_dyn_lds<&gemm_tn_256_kernel<5, false, true>>(5 * 32768)) return rc;
       if (int rc = ensure_dyn_lds<&gemm_tn_256_kernel<5, true, true>>(5 * 32768)) return rc;
-      if (colsum) gemm_tn_256_kernel<5, true, true><<<grid, 512, 5 * 32768, st>>>(Ab, Bb, slabs, M, N, K, kper2, colsum);
-      else gemm_tn_256_kernel<5, false, true><<<grid, 512, 5 * 32768, st>>>(Ab, Bb, slabs, M, N, K, kper2, nullptr);
-    } else if (colsum) gemm_tn_256_kernel<4, true><<<grid, 512, 4 * 32768, st>>>(Ab, Bb, slabs, M, N, K, kper2, colsum);
-    else if (nst == 3) gemm_tn_256_kernel<3, false><<<grid, 512, 3 * 32768, st>>>(Ab, Bb, slabs, M, N, K, kper2, nullptr);
-    else if (nst == 5) gemm_tn_256_kernel<5, false><<<grid, 512, 5 * 32768, st>>>(Ab, Bb, slabs, M, N, K, kper2, nullptr);
-    else gemm_tn_256_kernel<4, false><<<grid, 512, 4 * 32768, st>>>(Ab, Bb, slabs, M, N, K, kper2, nullptr);
+      if (colsum) gemm_tn_256_kernel<5, true, true><<<grid, 512, 5 * 32768, st>>>(Ab, Bb, slabs, M, N, K, kper2, colsum, a_blocked);
+      else gemm_tn_256_kernel<5, false, true><<<grid, 512, 5 * 32768, st>>>(Ab, Bb, slabs, M, N, K, kper2, nullptr, a_blocked);
+    } else if (colsum) gemm_tn_256_kernel<4, true><<<grid, 512, 4 * 32768, st>>>(Ab, Bb, slabs, M, N, K, kper2, colsum, a_blocked);
+    else if (nst == 3) gemm_tn_256_kernel<3, false><<<grid, 512, 3 * 32768, st>>>(Ab, Bb, slabs, M, N, K, kper2, nullptr, a_blocked);
+    else if (nst == 5) gemm_tn_256_kernel<5, false><<<grid, 512, 5 * 32768, st>>>(Ab, Bb, slabs, M, N, K, kper2, nullptr, a_blocked);
+    else gemm_tn_256_kernel<4, false><<<grid, 512, 4 * 32768, st>>>(Ab, Bb, slabs, M, N, K, kper2, nullptr, a_blocked);
     if (colsum && colsum_done) *colsum_done = 1;
     CSN_LAUNCH_CHECK();
     return CSN_OK;
@@ -1202,6 +1212,6 @@ extern "C" int csn_gemm_tn(const void* A, const void* B, float* C, int64_t M, in
   CSN_REQUIRE(dtype == CSN_F32 || dtype == CSN_BF16, "csn_gemm_tn: bad dtype %d", dtype);
   hipStream_t st = as_stream(stream);
   int S = 1;
-  if (int rc = launch_gemm_tn_slabs(A, B, (float*)scratch, M, N, K, dtype, st, &S, nullptr, nullptr, options_from_env())) return rc;
+  if (int rc = launch_gemm_tn_slabs(A, B, (float*)scratch, M, N, K, dtype, st, &S, nullptr, nullptr, options_from_env(), 0)) return rc;
   return launch_reduce_slabs((const float*)scratch, M * N, S, C, M * N, 0, st);
 }

@@ -9,6 +9,7 @@
 // asm with counted lgkmcnt; here 4 waves (2 x 2) of 128 x 64 outputs each.  K % 64 == 0, N % 4 == 0.
 #pragma once
 #include "csn_common.h"
+#include "lstm_cell_common.h"
 #include "lstm_cell_blk.h"
 
 namespace csn {
@@ -69,7 +70,10 @@ __device__ __forceinline__ void beside_gemm_tiles(const BesideGemm& g, char* sme
         const int ch = (lane & 7) ^ ((row >> 1) & 7);
         int64_t am = m0 + row;
         am = am < M ? am : M - 1;
-        beside_glds16(g.A + am * K + (int64_t)kt * 64 + ch * 8, a_s + (4 * i + wave) * 1024);
+        // (a_blocked: A in the recurrence's fragment-major layout -- the same 16-byte pieces at other addresses)
+        const bf16_t* asrc = g.a_blocked ? g.A + blk_offset(am, (int64_t)kt * 64 + ch * 8, K)
+                                         : g.A + am * K + (int64_t)kt * 64 + ch * 8;
+        beside_glds16(asrc, a_s + (4 * i + wave) * 1024);
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {

@@ -278,6 +278,7 @@ struct csnLstmPlan {
   csn::WsLayout w;
   csn::SideCtx sc;
   csn::Prof prof;
+  int dgates_copies = 0;      // what the last backward wrote per step (csn_lstm_plan_dgates_copies)
 };
 
 using namespace csn;
@@ -322,6 +323,8 @@ extern "C" int csn_lstm_plan_path(const csnLstmPlan* P) {
   if (P == nullptr) return -1;
   return P->w.persist_bwd ? 3 : (P->w.persist ? 2 : (P->w.il ? 1 : 0));
 }
+
+extern "C" int csn_lstm_plan_dgates_copies(const csnLstmPlan* P) { return P == nullptr ? -1 : P->dgates_copies; }
 
 extern "C" int csn_lstm_profile_enable(csnLstmPlan* P, int on) {
   CSN_REQUIRE(P != nullptr, "csn_lstm_profile_enable: null plan");
@@ -394,6 +397,16 @@ extern "C" int csn_lstm_status_read(const csnLstmPlan* P, const void* workspace,
   unsigned flag[3] = {0u, 0u, 0u};
   CSN_HIP_CHECK(hipMemcpy(flag, (const char*)workspace + P->w.status, sizeof(flag), hipMemcpyDeviceToHost));
   *status = (flag[0] ? CSN_STATUS_TIMEOUT : 0) | (flag[1] ? CSN_STATUS_NONFINITE : 0) | (flag[2] ? CSN_STATUS_STALE_SLOT : 0);
+#ifdef CSN_SLAB_TAGS
+  if (flag[2] && getenv("CSN_TAGS_VERBOSE")) {
+    unsigned dbg[24];
+    CSN_HIP_CHECK(hipMemcpy(dbg, (const char*)workspace + P->w.status + 28, sizeof(dbg), hipMemcpyDeviceToHost));
+    if (dbg[0])
+      fprintf(stderr, "stale piece (backward): t=%u step-in-launch=%u group=%u slice=%u wave=%u lane=%u kb*4+rg=%u u0=%08x local=%u redone=%u "
+              "single=%u phase=%u rot=%u nsteps=%u xcc=%u lanes=%u\n", dbg[1], dbg[2], dbg[3], dbg[4], dbg[5], dbg[6], dbg[7], dbg[8],
+              dbg[9], dbg[10], dbg[11], dbg[12], dbg[13], dbg[14], dbg[15], dbg[16]);
+  }
+#endif
   return CSN_OK;
 }
 
@@ -968,6 +981,7 @@ static int backward_persist(Plan& P, char* ws, const float* dy_last,
   CSN_HIP_CHECK(hipMemsetAsync(ws + w.zero_bwd, 0, w.zero_bwd_bytes, st));
   const bool try_local = !P.opt.no_xcd_local;
 
+  int single_copy = 0;       // (decided below, before the first launch)
   // weight / bias gradients of one layer (its recurrence complete): four launches on stream `on`
   auto weight_grads = [&](int l, hipStream_t on, size_t scratch_off, size_t colsum_off) -> int {
     const LayerWs& L = w.layer[l];
@@ -977,13 +991,16 @@ static int backward_persist(Plan& P, char* ws, const float* dy_last,
     float* slabs = (float*)(ws + scratch_off);
     int S = 1, r;
     int cs_done = 0, S_cs = 1;
-    if ((r = launch_gemm_tn_slabs(ws + L.dgates, ws + L.h_all, slabs, G, H, TB, CSN_BF16, on, &S, (float*)(ws + colsum_off), &cs_done, P.opt))) return r;
+    const int blocked = single_copy;
+    const char* dgm = ws + (blocked ? L.dg_blk_all : L.dgates);
+    if ((r = launch_gemm_tn_slabs(dgm, ws + L.h_all, slabs, G, H, TB, CSN_BF16, on, &S, (float*)(ws + colsum_off), &cs_done, P.opt, blocked))) return r;
     S_cs = S;
     if ((r = launch_reduce_slabs_unperm(slabs, G * H, S, H, H, dw_hh[l], on))) return r;
-    if ((r = launch_gemm_tn_slabs(ws + L.dgates, inp, slabs, G, I, TB, CSN_BF16, on, &S, nullptr, nullptr, P.opt))) return r;
+    if ((r = launch_gemm_tn_slabs(dgm, inp, slabs, G, I, TB, CSN_BF16, on, &S, nullptr, nullptr, P.opt, blocked))) return r;
     if ((r = launch_reduce_slabs_unperm(slabs, G * I, S, H, I, dw_ih[l], on))) return r;
     // bias gradient = column sums of dgates: partial sums come out of the dW_hh GEMM when its kernel provides them
     if (!cs_done) {
+      if (blocked) return fail(CSN_ERR_UNSUPPORTED, "backward_persist: single-copy mode without the weight-gradient kernel's column sums");
       if ((r = launch_colsum_partial(ws + L.dgates, TB, G, CSN_BF16, ws + colsum_off, on))) return r;
       S_cs = colsum_chunks();
     }
@@ -1012,9 +1029,24 @@ static int backward_persist(Plan& P, char* ws, const float* dy_last,
 #ifdef CSN_SLAB_TAGS
   if (a.data_polls && P.opt.tags_no_rearm) a.data_polls |= 4;
 #endif
-  if (a.data_polls)        // the ring of 4 hand-off slabs of every layer starts as sentinel (lstm_bwd_persist.hip)
+  // CSN_BWD_SINGLE_COPY (experiments library only): ONE copy of dgates (lstm_bwd_persist.hip, SINGLE) --
+  // the hand-off slabs, one per step, fragment-major, are what the GEMMs after the recurrence read, and the row-major
+  // copy is not written (4 of the 12 store instructions of a step).  Possible when every reader of dgates takes the
+  // block layout: the weight gradients on the 256 x 256 kernel (which also delivers the bias gradient), the input
+  // gradients of the upper layers inside the launch (gemm_beside.h), and nobody wants dx of layer 0.
+  const int64_t I0 = d->I;
+  const bool single = a.data_polls != 0 && P.opt.bwd_single_copy && dx == nullptr && !wg_overlap && B == Bpad &&
+                      (NL == 1 || beside) && (int64_t)T * Bpad * G * 2 < ((int64_t)1 << 31) &&
+                      gemm_tn_takes_blocked_a(G, H, TB, P.opt) && gemm_tn_takes_blocked_a(G, I0, TB, P.opt);
+  a.single_copy = single_copy = single ? 1 : 0;
+  P.dgates_copies = single ? 1 : 2;
+  if (a.data_polls) {
+    // the hand-off slabs that are polled before a kernel has armed them start as sentinel: the ring of 4, or (single
+    // copy) the slabs of steps T-1 and T-2 -- slab s <= T-3 is armed by its producers at step s+2
+    const int first = single ? (T >= 2 ? T - 2 : 0) : 0, count = single ? T - first : 4;
     for (int l = 0; l < NL; ++l)
-      CSN_HIP_CHECK(hipMemsetAsync(ws + w.layer[l].dg_blk_all, 0xff, (size_t)4 * Bpad * G * 2, st));
+      CSN_HIP_CHECK(hipMemsetAsync(ws + w.layer[l].dg_blk_all + (size_t)first * Bpad * G * 2, 0xff, (size_t)count * Bpad * G * 2, st));
+  }
   int n_launch = 0;
   BesideGemm pending[3];           // GEMMs of the chunks finished by the previous launch
   int npending = 0;
@@ -1062,11 +1094,11 @@ static int backward_persist(Plan& P, char* ws, const float* dy_last,
       // dx_l[chunk] = dgates_l[chunk] (interleaved K) * W_ih;  Bt = W_ih^T [I, 4H']
       const LayerWs& L = w.layer[l];
       const int t_hi = T - 1 - chk[i] * Cz, t_lo = t_hi - a.slot[i].nsteps + 1;
-      const bf16_t* Ag = (const bf16_t*)(ws + L.dgates) + (size_t)t_lo * B * G;
+      const bf16_t* Ag = (const bf16_t*)(ws + (a.single_copy ? L.dg_blk_all : L.dgates)) + (size_t)t_lo * B * G;
       float* Cg = (float*)(ws + L.dx) + (size_t)t_lo * B * H;
       const int64_t Mg = (int64_t)(t_hi - t_lo + 1) * B;
       if (beside) {
-        pending[npending++] = BesideGemm{Ag, (const bf16_t*)(ws + L.wiht), Cg, (int)Mg, H, (int)G, nullptr, nullptr, 0};
+        pending[npending++] = BesideGemm{Ag, (const bf16_t*)(ws + L.wiht), Cg, (int)Mg, H, (int)G, nullptr, nullptr, 0, a.single_copy};
       } else {
         if ((rc = gemm_nt(Ag, ws + L.wiht, nullptr, Cg, Mg, H, G, CSN_BF16, CSN_F32, 0, st, P.opt))) return rc;
       }

@@ -70,7 +70,7 @@ __device__ __forceinline__ void bstore_b128(__amdgpu_buffer_rsrc_t rsrc, unsigne
   __builtin_amdgcn_raw_buffer_store_b128(cvt.u, rsrc, (int)byte_off, soff, WT ? 16 : 0);   // sc1 = write-through
 }
 
-template <int NUT, int KS, bool DPOLL>
+template <int NUT, int KS, bool DPOLL, bool SINGLE = false>
 __global__ void __launch_bounds__(256) lstm_bwd_persist_kernel(PersistBwdArgs a) {
 #ifndef CSN_BWD_RING
 #define CSN_BWD_RING 5
@@ -129,6 +129,12 @@ __global__ void __launch_bounds__(256) lstm_bwd_persist_kernel(PersistBwdArgs a)
   // hand-off by DATA (see lstm_fwd_persist.hip): ring of 4 slabs, dgates_s in slot s & 3, unwritten regions hold the
   // all-ones sentinel; no store drain and no flag on the producer side
   constexpr bool dpoll = DPOLL;
+  // SINGLE (a.single_copy; experiments library only): one copy of dgates.  Every step has a slab of its own (dgates_s at dg_blk_all + s slab), which
+  // the weight- and input-gradient GEMMs read in place (fragment-major A); the row-major copy is not written.  The
+  // hand-off protocol is the ring's with `& 3` dropped: a producer arms ITS region of slab t - 2 at step t (the host arms
+  // slabs T-1 and T-2), so every argument about the order of arming, publishing and polling carries over unchanged.
+  static_assert(!SINGLE || DPOLL, "single-copy mode hands off by data");
+  auto slab_of = [](int s) { return SINGLE ? s : (s & 3); };
 
   // ---- is this group on one XCD?  (see lstm_fwd_persist.hip)
   bool local = false;
@@ -214,13 +220,29 @@ __global__ void __launch_bounds__(256) lstm_bwd_persist_kernel(PersistBwdArgs a)
   // data polls: ONE buffer resource over the ring of 4 slabs, the slab of a step is a scalar offset -- a resource per
   // slab and use (read, write, re-arm) ran the kernel out of SGPRs; flags: a resource per slab (T slabs can exceed 2 GiB)
   const __amdgpu_buffer_rsrc_t ring_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)dg_blk_all, 0, (int)((size_t)4 * slab * 2), 0x00020000);
+      (void*)dg_blk_all, 0, (int)((size_t)(SINGLE ? T : 4) * slab * 2), 0x00020000);
   const int slab_bytes = (int)(slab * 2);
 #ifdef CSN_PSTAMPS
   unsigned long long last_ = wall_clock64();
   if (tid == 0 && blockIdx.x == CSN_STAMP_BLOCK) atomicAdd(&g_bstamps[6], last_ - t_entry_);   // prologue of this launch
 #endif
 
+  // data polls: sentinel over this workgroup's region of the slab at byte offset arm_off of the ring / slab array
+  auto arm_region = [&](int arm_off) {
+    const bf16x8 sent = __builtin_bit_cast(bf16x8, (u32x4){0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu});
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+      const unsigned o0 = (unsigned)(blk_offset(prow[ps], 4 * (int64_t)puq[ps], K) * 2);
+      const unsigned o1 = (unsigned)(blk_offset(prow[ps], 4 * (int64_t)puq[ps] + 8, K) * 2);
+      if (local) {
+        bstore_b128<false>(ring_rsrc, o0, sent, arm_off);
+        bstore_b128<false>(ring_rsrc, o1, sent, arm_off);
+      } else {
+        bstore_b128<true>(ring_rsrc, o0, sent, arm_off);
+        bstore_b128<true>(ring_rsrc, o1, sent, arm_off);
+      }
+    }
+  };
   for (int s = 0; s < nsteps; ++s) {
     const int t = t_hi - s;
     bf16x8 gt[NPASS][2];
@@ -253,7 +275,7 @@ __global__ void __launch_bounds__(256) lstm_bwd_persist_kernel(PersistBwdArgs a)
           const int pi = lane < 4 * npw ? lane >> 2 : 0, pw = lane & 3;
           const int pp = 64 * pw + 63 + (NPASS - 1) * 256;                 // (NPAIR is a multiple of 256: every thread has a pair in the last pass)
           const int64_t prow_w = m0 + pp / QPR, pcol_w = 4 * (int64_t)((wave * npw + pi) * 16 * NUT + 4 * (pp % QPR)) + 8;
-          fl = reinterpret_cast<const unsigned*>(dg_blk_all + (size_t)((t + 1) & 3) * slab + blk_offset(prow_w, pcol_w, K));
+          fl = reinterpret_cast<const unsigned*>(dg_blk_all + (size_t)slab_of(t + 1) * slab + blk_offset(prow_w, pcol_w, K));
         } else {
           fl = flags + (size_t)(t + 1) * flag_step + wave * npw + (lane < npw ? lane : 0);
         }
@@ -272,7 +294,7 @@ __global__ void __launch_bounds__(256) lstm_bwd_persist_kernel(PersistBwdArgs a)
       CSN_BSTAMP(0);   // wait for dgates_{t+1}
       const __amdgpu_buffer_rsrc_t slabs_rsrc = dpoll ? ring_rsrc : __builtin_amdgcn_make_buffer_rsrc(
           (void*)(dg_blk_all + (size_t)(t + 1) * slab), 0, slab_bytes, 0x00020000);
-      const int src_off = dpoll ? __builtin_amdgcn_readfirstlane(((t + 1) & 3) * slab_bytes) : 0;
+      const int src_off = dpoll ? __builtin_amdgcn_readfirstlane(slab_of(t + 1) * slab_bytes) : 0;
       // (the k-block walk offset re-enters the step as an opaque scalar: left visible as a loop invariant, the compiler
       // keeps the 24 rotated block offsets of every load in SGPRs across the steps and runs out of them)
       int rot_t = rot;
@@ -311,6 +333,8 @@ __global__ void __launch_bounds__(256) lstm_bwd_persist_kernel(PersistBwdArgs a)
         }
 #ifdef CSN_SLAB_TAGS
         bool stale = false;       // (debug library, see lstm_fwd_persist.hip: a non-sentinel piece with the wrong step tag)
+        int stale_kb = -1;
+        unsigned stale_u0 = 0;
 #endif
 #pragma unroll
         for (int kb = 0; kb < KS; ++kb) {
@@ -320,7 +344,9 @@ __global__ void __launch_bounds__(256) lstm_bwd_persist_kernel(PersistBwdArgs a)
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
               const u32x4 u = __builtin_bit_cast(u32x4, df[kb % RING][rg]);
-              stale |= u[0] != 0xffffffffu && (u[0] & 1u) != want;
+              const bool bad = u[0] != 0xffffffffu && (u[0] & 1u) != want;
+              if (bad && stale_kb < 0) { stale_kb = kb * 4 + rg; stale_u0 = u[0]; }
+              stale |= bad;
             }
           }
 #endif
@@ -337,6 +363,15 @@ __global__ void __launch_bounds__(256) lstm_bwd_persist_kernel(PersistBwdArgs a)
         }
 #ifdef CSN_SLAB_TAGS
         if (__any(stale) && lane == 0) __hip_atomic_store(a.error_flag + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (stale) {     // first detection of the workspace: where it was (read back by csn_lstm_status_read of the debug library)
+          if (atomicCAS(a.error_flag + 7, 0u, 1u) == 0u) {
+            unsigned* dbg = a.error_flag + 8;
+            dbg[0] = (unsigned)t; dbg[1] = (unsigned)s; dbg[2] = (unsigned)grp; dbg[3] = (unsigned)slice; dbg[4] = (unsigned)wave;
+            dbg[5] = (unsigned)lane; dbg[6] = (unsigned)stale_kb; dbg[7] = stale_u0; dbg[8] = (unsigned)local; dbg[9] = (unsigned)redone;
+            dbg[10] = (unsigned)SINGLE; dbg[11] = (unsigned)(((t + 1) >> 2) & 1); dbg[12] = (unsigned)rot_t; dbg[13] = (unsigned)nsteps;
+            dbg[14] = __builtin_amdgcn_s_getreg(6164) & 7u; dbg[15] = (unsigned)__popcll(__ballot(stale));
+          }
+        }
 #endif
         again = false;
         if constexpr (dpoll) {
@@ -400,27 +435,14 @@ __global__ void __launch_bounds__(256) lstm_bwd_persist_kernel(PersistBwdArgs a)
     // data polls: re-arm slot (t - 2) & 3 (it holds dgates_{t+2}: every producer has published dgates_{t+1}, so all of
     // them have read it; it is looked at again at step t-3, after this workgroup's dgates_{t-1} was consumed, which
     // is stored behind loads that retire these stores -- the argument of lstm_fwd_persist.hip, mirrored in time)
-    if (dpoll && !CSN_DPOLL_NO_REARM(a.data_polls)) {
-      const int arm_off = __builtin_amdgcn_readfirstlane(((t + 2) & 3) * slab_bytes);
-      const bf16x8 sent = __builtin_bit_cast(bf16x8, (u32x4){0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu});
-#pragma unroll
-      for (int ps = 0; ps < NPASS; ++ps) {
-        const unsigned o0 = (unsigned)(blk_offset(prow[ps], 4 * (int64_t)puq[ps], K) * 2);
-        const unsigned o1 = (unsigned)(blk_offset(prow[ps], 4 * (int64_t)puq[ps] + 8, K) * 2);
-        if (local) {
-          bstore_b128<false>(ring_rsrc, o0, sent, arm_off);
-          bstore_b128<false>(ring_rsrc, o1, sent, arm_off);
-        } else {
-          bstore_b128<true>(ring_rsrc, o0, sent, arm_off);
-          bstore_b128<true>(ring_rsrc, o1, sent, arm_off);
-        }
-      }
+    if (dpoll && !CSN_DPOLL_NO_REARM(a.data_polls) && (!SINGLE || t >= 2)) {
+      arm_region(__builtin_amdgcn_readfirstlane((SINGLE ? t - 2 : ((t + 2) & 3)) * slab_bytes));
       __builtin_amdgcn_sched_barrier(0);
     }
 
     const __amdgpu_buffer_rsrc_t slabs_rsrc = dpoll ? ring_rsrc : __builtin_amdgcn_make_buffer_rsrc(
         (void*)(dg_blk_all + (size_t)t * slab), 0, slab_bytes, 0x00020000);
-    const int dst_off = dpoll ? __builtin_amdgcn_readfirstlane((t & 3) * slab_bytes) : 0;
+    const int dst_off = dpoll ? __builtin_amdgcn_readfirstlane(slab_of(t) * slab_bytes) : 0;
 #pragma unroll
     for (int ps = 0; ps < NPASS; ++ps) {
       if (!pok[ps]) {
@@ -479,8 +501,9 @@ __global__ void __launch_bounds__(256) lstm_bwd_persist_kernel(PersistBwdArgs a)
 #ifdef CSN_SLAB_TAGS      // each 16-byte hand-off piece carries bit 2 of its step in the lowest mantissa bit of its first element
       {
         u32x4 ul = __builtin_bit_cast(u32x4, lo), uh = __builtin_bit_cast(u32x4, hi);
-        ul[0] = (ul[0] & ~1u) | (unsigned)((t >> 2) & 1);
-        uh[0] = (uh[0] & ~1u) | (unsigned)((t >> 2) & 1);
+        const unsigned tag = (unsigned)((t >> 2) & 1);
+        ul[0] = (ul[0] & ~1u) | tag;
+        uh[0] = (uh[0] & ~1u) | tag;
         lo = __builtin_bit_cast(bf16x8, ul);
         hi = __builtin_bit_cast(bf16x8, uh);
       }
@@ -492,9 +515,11 @@ __global__ void __launch_bounds__(256) lstm_bwd_persist_kernel(PersistBwdArgs a)
         bstore_b128<true>(slabs_rsrc, o0, lo, dst_off);
         bstore_b128<true>(slabs_rsrc, o1, hi, dst_off);
       }
-      bf16x8* op = reinterpret_cast<bf16x8*>(dgates + ((size_t)t * B + row) * K + 4 * (size_t)uq);
-      nt_store(op, lo);
-      nt_store(op + 1, hi);
+      if constexpr (!SINGLE) {
+        bf16x8* op = reinterpret_cast<bf16x8*>(dgates + ((size_t)t * B + row) * K + 4 * (size_t)uq);
+        nt_store(op, lo);
+        nt_store(op + 1, hi);
+      }
       dcn[ps] = make_float4(dcarry[0], dcarry[1], dcarry[2], dcarry[3]);
       cc[ps] = cpv[ps];                       // c_{t-1} is the next step's c
     }
@@ -526,6 +551,9 @@ static int launch_bwd_persist_t(const PersistBwdArgs& a, hipStream_t st) {
   size_t lds = (size_t)4 * 4 * NUT * kBwdRedTile * sizeof(float4);
   if (int rc = ensure_dyn_lds<&lstm_bwd_persist_kernel<NUT, KS, false>>((int)kBesideLdsBytes + 64)) return rc;
   if (int rc = ensure_dyn_lds<&lstm_bwd_persist_kernel<NUT, KS, true>>((int)kBesideLdsBytes + 64)) return rc;
+#ifdef CSN_EXPERIMENTS
+  if (int rc = ensure_dyn_lds<&lstm_bwd_persist_kernel<NUT, KS, true, true>>((int)kBesideLdsBytes + 64)) return rc;
+#endif
   const unsigned nslices = (unsigned)(a.H / (16 * NUT));
   PersistBwdArgs b = a;
   if (b.xcd_groups) {
@@ -537,6 +565,10 @@ static int launch_bwd_persist_t(const PersistBwdArgs& a, hipStream_t st) {
     }
   }
   const unsigned grid = b.xcd_groups ? 8u * (unsigned)b.grid_slices : nslices * (unsigned)(b.MT * b.nslots);
+#ifdef CSN_EXPERIMENTS
+  if (b.data_polls && b.single_copy) lstm_bwd_persist_kernel<NUT, KS, true, true><<<dim3(grid), 256, lds, st>>>(b);
+  else
+#endif
   if (b.data_polls) lstm_bwd_persist_kernel<NUT, KS, true><<<dim3(grid), 256, lds, st>>>(b);
   else lstm_bwd_persist_kernel<NUT, KS, false><<<dim3(grid), 256, lds, st>>>(b);
   CSN_LAUNCH_CHECK();
@@ -549,6 +581,11 @@ int launch_bwd_persist(const PersistBwdArgs& a, hipStream_t st) {
   CSN_REQUIRE(ns % 4 == 0 && ns <= kPersistFlagLine, "launch_bwd_persist: H=%d gives %d slices", a.H, ns);
   if (a.xcd_groups) CSN_REQUIRE(a.nslots * a.MT <= 8, "launch_bwd_persist: groups do not fit 8 XCDs");
   CSN_REQUIRE(a.ngemm >= 0 && a.ngemm <= 3 && (a.ngemm == 0 || a.xcd_groups), "launch_bwd_persist: bad GEMM list");
+#ifndef CSN_EXPERIMENTS
+  CSN_REQUIRE(!a.single_copy, "launch_bwd_persist: the single-copy form lives in the experiments library");
+#endif
+  CSN_REQUIRE(!a.single_copy || (a.data_polls && a.B == a.Bpad && (int64_t)a.T * a.Bpad * a.H * 8 < (int64_t)1 << 31),
+              "launch_bwd_persist: single-copy mode needs data polls, B %% 64 == 0 and T slabs below 2 GiB");
   for (int i = 0; i < a.ngemm; ++i)
     CSN_REQUIRE(a.gemm[i].K % 64 == 0 && a.gemm[i].N % 4 == 0 && a.gemm[i].M > 0, "launch_bwd_persist: GEMM %d shape", i);
   switch (a.H) {

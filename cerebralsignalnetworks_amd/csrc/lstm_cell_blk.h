@@ -75,6 +75,7 @@ struct BesideGemm {
   const float* bias;       // [N] added to every row, or null
   unsigned* counter;       // atomic tile counter (zeroed by the host), or null: tiles dealt round-robin to the workers
   int c_bf16;              // != 0: C is bf16 (the forward's input projection, consumed only by lstm_fwd_ns.hip)
+  int a_blocked;           // != 0: A is in the fragment-major 16 x 32 block layout (blk_offset; M % 16 == 0), not row-major
 };
 static constexpr int kPersistFlagLine = 32;    // one 128-byte line per (slot, M-tile): at most 32 slices
 struct PersistFwdArgs {
@@ -131,6 +132,9 @@ struct PersistBwdArgs {
   int xcd_groups;
   int rotate;              // != 0: each workgroup walks the k-blocks from its own offset (changes the summation order)
   int data_polls;          // hand-off by sentinel data in a ring of 4 slabs (the host fills them with 0xff per backward)
+  int single_copy;         // (experiments library) != 0: ONE copy of dgates -- every step's hand-off slab has an address of its own (dg_blk_all[t],
+                           // sentinel-armed two steps ahead by its producer) and IS what the weight- and input-gradient
+                           // GEMMs read; the row-major copy is not written (4 of the 12 store instructions of a step)
   unsigned long long* agree;
   unsigned* error_flag;
   int B, H, T, Bpad, MT;

@@ -36,7 +36,7 @@ enum csnStatus {
 enum csnDtype { CSN_F32 = 0, CSN_BF16 = 1 };
 
 /* ABI version of this header; bumped on any signature change. */
-#define CSN_ABI_VERSION 3
+#define CSN_ABI_VERSION 4
 int csn_abi_version(void);
 /* Thread-local message for the last non-zero status returned on this thread. */
 const char* csn_last_error(void);
@@ -102,6 +102,11 @@ size_t csn_lstm_plan_workspace_bytes(const csnLstmPlan* plan);
 /* Which kernels the plan runs: 0 generic per-step cells (exact f32 / odd shapes), 1 per-diagonal bf16 launches,
  * 2 weight-stationary forward, 3 weight-stationary forward and backward. */
 int csn_lstm_plan_path(const csnLstmPlan* plan);
+/* Copies of the gate gradients the plan's LAST csn_lstm_backward wrote per step: 2 = the fragment-major hand-off slab
+ * and a row-major copy for the GEMMs behind the recurrence (always, in this library); 1 = the hand-off slabs alone,
+ * read in place by those GEMMs (experiments library under CSN_BWD_SINGLE_COPY); 0 = no backward has
+ * run, or a path without hand-off slabs.  Diagnostic: lets a test see which form it compared. */
+int csn_lstm_plan_dgates_copies(const csnLstmPlan* plan);
 /* Same number without a plan (what csn_lstm_plan_workspace_bytes would return for a plan created now). */
 size_t csn_lstm_workspace_bytes(const csnLstmDesc* d, int training);
 

@@ -451,20 +451,24 @@ def test_end_to_end_step_loss_within_1e4(cuda):
 # ----------------------------------------------------------------------------------------------
 # bf16 fast path ("il": fragment-major, gate-interleaved, layer wavefront, side-stream GEMMs)
 # ----------------------------------------------------------------------------------------------
-def _run_lstm(p, x, dy_all, dy_last, C, H, L, dtype, cuda, env=None):
+def _run_lstm(p, x, dy_all, dy_last, C, H, L, dtype, cuda, env=None, want_dx=True, info=None):
     env = env or {}
     old = {k: os.environ.get(k) for k in env}
     os.environ.update(env)
     try:
         m = _model_from_params(p, C, H, L, 8, None, dtype, cuda)
-        xt = dev_t(x, cuda).requires_grad_(True)
+        xt = dev_t(x, cuda).requires_grad_(want_dx)
         y_all, y_last = m.lstm(xt, want_all=True)
         loss = (y_all * dev_t(dy_all, cuda)).sum() + (y_last * dev_t(dy_last, cuda)).sum()
         loss.backward()
         torch.cuda.synchronize()
         for plan in m.lstm.all_plans():
             assert plan.status() == 0, "an in-kernel hand-off of the weight-stationary forward timed out"
-        out = dict(y_all=y_all.detach().cpu().numpy(), dx=xt.grad.cpu().numpy())
+        out = dict(y_all=y_all.detach().cpu().numpy())
+        if want_dx:
+            out["dx"] = xt.grad.cpu().numpy()
+        if info is not None:
+            info["dgates_copies"] = [plan.dgates_copies() for plan in m.lstm.all_plans()]
         for n, q in m.lstm.named_parameters():
             out[n] = q.grad.cpu().numpy()
         return out

@@ -24,6 +24,8 @@ def bench(name, fn, flops, reps=20):
 K, M, N = 128000, 3072, 768
 a, b = rnd(K, M), rnd(K, N)
 bench("tn 3072x768x128000", lambda: cabi.gemm_tn(a, b), 2.0 * K * M * N)
+b128 = rnd(K, 128)
+bench("tn 3072x128x128000", lambda: cabi.gemm_tn(a, b128), 2.0 * K * M * 128)
 a2, b2 = rnd(8192, 768), rnd(3072, 768)
 bias = torch.randn(3072, device=dev)
 out = torch.empty(8192, 3072, device=dev)
