@@ -47,6 +47,8 @@
 #endif
 // diagnostic build only (tools/persist_bench.hip): per-phase wall-clock sums of workgroup (0,0)
 __device__ unsigned long long g_pstamps[16];
+__device__ unsigned long long g_span[5] = {~0ull, 0ull, ~0ull, 0ull, 0ull};
+__device__ unsigned long long g_grp_alive[32];      // [0..7] ticks alive summed per group (slice 0 only), [8..15] launches, [16..23] ticks in the step loop, [24..31] steps
 #define CSN_PSTAMP(i)                                                          \
   do {                                                                         \
     __builtin_amdgcn_sched_barrier(0);                                         \
@@ -60,6 +62,32 @@ __device__ unsigned long long g_pstamps[16];
 #else
 #define CSN_PSTAMP(i)
 #endif
+#ifdef CSN_PSTAMPS
+// (diagnostic: how long the launch's waves were alive -- first entry to last exit over all workgroups -- to set against
+// the duration rocprofv3 reports for the dispatch, which also holds the dispatch itself and the end-of-kernel cache
+// write-back)
+__device__ __forceinline__ void span_exit(unsigned long long t_entry) {
+  if (threadIdx.x != 0) return;
+  const unsigned long long t_exit = wall_clock64();
+  atomicMin(&g_span[0], t_entry);
+  atomicMax(&g_span[1], t_entry);
+  atomicMin(&g_span[2], t_exit);
+  atomicMax(&g_span[3], t_exit);
+  __threadfence();
+  if (atomicAdd(&g_span[4], 1ull) + 1ull == (unsigned long long)gridDim.x) {      // the last workgroup out
+    __threadfence();
+    const unsigned long long e0 = atomicAdd(&g_span[0], 0ull), e1 = atomicAdd(&g_span[1], 0ull);
+    const unsigned long long x0 = atomicAdd(&g_span[2], 0ull), x1 = atomicAdd(&g_span[3], 0ull);
+    atomicAdd(&g_pstamps[10], x1 - e0);      // waves alive
+    atomicAdd(&g_pstamps[11], e1 - e0);      // entry skew
+    atomicAdd(&g_pstamps[12], x1 - x0);      // exit skew
+    atomicAdd(&g_pstamps[13], 1ull);         // launches
+    g_span[0] = ~0ull; g_span[1] = 0ull; g_span[2] = ~0ull; g_span[3] = 0ull; g_span[4] = 0ull;
+    __threadfence();
+  }
+}
+#endif
+
 
 namespace csn {
 
@@ -146,7 +174,12 @@ __global__ void __launch_bounds__(256) lstm_fwd_persist_kernel(PersistFwdArgs a)
   if (a.xcd_groups) {
     grp = blockIdx.x & 7;
     slice = blockIdx.x >> 3;
-    if (grp >= a.nslots * MT) return;
+    if (grp >= a.nslots * MT) {
+#ifdef CSN_PSTAMPS
+      span_exit(t_entry_);
+#endif
+      return;
+    }
   } else {
     grp = blockIdx.x / nslices;
     slice = blockIdx.x % nslices;
@@ -262,6 +295,7 @@ __global__ void __launch_bounds__(256) lstm_fwd_persist_kernel(PersistFwdArgs a)
 #ifdef CSN_PSTAMPS
   unsigned long long last_ = wall_clock64();
   if (tid == 0 && blockIdx.x == CSN_STAMP_BLOCK) atomicAdd(&g_pstamps[6], last_ - t_entry_);   // prologue of this launch
+  const unsigned long long t_loop_ = last_;
 #endif
 
   auto request_input = [&](int t) {
@@ -586,6 +620,17 @@ __global__ void __launch_bounds__(256) lstm_fwd_persist_kernel(PersistFwdArgs a)
     }
     CSN_PSTAMP(5);     // signal
   }
+#ifdef CSN_PSTAMPS
+  __syncthreads();
+  if (tid == 0 && slice == 0) {
+    const unsigned long long now_ = wall_clock64();
+    atomicAdd(&g_grp_alive[grp & 7], now_ - t_entry_);
+    atomicAdd(&g_grp_alive[8 + (grp & 7)], 1ull);
+    atomicAdd(&g_grp_alive[16 + (grp & 7)], now_ - t_loop_);
+    atomicAdd(&g_grp_alive[24 + (grp & 7)], (unsigned long long)nsteps);
+  }
+  span_exit(t_entry_);
+#endif
 }
 
 // The weight-stationary kernels place one workgroup per CU and need all of a launch co-resident: they are used
@@ -641,6 +686,12 @@ int launch_fwd_persist(const PersistFwdArgs& a, hipStream_t st) {
 
 #ifdef CSN_PSTAMPS
 // diagnostic build only (make diag): read and clear the per-phase tick sums
+extern "C" int csn_debug_read_grp_alive(unsigned long long* out) {
+  unsigned long long z[32] = {0};
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_grp_alive), sizeof(z)) != hipSuccess) return 1;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_grp_alive), z, sizeof(z)) != hipSuccess) return 1;
+  return 0;
+}
 extern "C" int csn_debug_read_pstamps(unsigned long long* out) {
   unsigned long long z[16] = {0};
   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pstamps), sizeof(z)) != hipSuccess) return 1;

@@ -44,6 +44,18 @@ for it in range(4):
         if name == "fwd-nsplit":
             print("   nsplit detail per-step us: dma issue %.2f | x-mfma + input request %.2f | wait g0 %.2f | g0 mfma + wait g1 %.2f | g1,g2 mfma + waits %.2f | (g3 mfma in loads+mfma rest)"
                   % tuple(buf[i] * 0.01 / T for i in (8, 9, 10, 11, 12)))
+        if name == "fwd-ksplit" and buf[13]:
+            n = buf[13]
+            print("   fwd launches %d: waves alive (first entry -> last exit) %.1f us | entry skew %.1f | exit skew %.1f   (rocprofv3's dispatch duration also holds the dispatch and the end-of-kernel write-back)"
+                  % (n, buf[10] * 0.01 / n, buf[11] * 0.01 / n, buf[12] * 0.01 / n))
+        if name == "fwd-ksplit" and hasattr(lib, "csn_debug_read_grp_alive"):
+            g = (ctypes.c_ulonglong * 32)()
+            lib.csn_debug_read_grp_alive.argtypes = [ctypes.POINTER(ctypes.c_ulonglong)]
+            lib.csn_debug_read_grp_alive(g)
+            print("   fwd workgroup alive per launch, by hand-off group (slice 0; us, launches): " +
+                  " ".join("g%d %.1f (%d)" % (i, g[i] * 0.01 / max(1, g[8 + i]), g[8 + i]) for i in range(8)))
+            print("   fwd step loop per launch / per step, by group: " +
+                  " ".join("g%d %.1f / %.2f" % (i, g[16 + i] * 0.01 / max(1, g[8 + i]), g[16 + i] * 0.01 / max(1, g[24 + i])) for i in range(8)))
         if name == "fwd-ksplit":
             print("   fwd epilogue detail per-step us: pass 0 reads + math %.2f | pass 0 store issue %.2f | (rest of 'epilogue' = the split pass)" % (buf[8] * 0.01 / T, buf[9] * 0.01 / T))
         print("step %d %s per-step us: wait %.2f | loads+mfma %.2f | lds/gate-math %.2f | epilogue %.2f | drain %.2f | signal %.2f | sum %.2f | prologue per launch %.1f us"
