@@ -1036,7 +1036,7 @@ static int backward_persist(Plan& P, char* ws, const float* dy_last,
   // gradients of the upper layers inside the launch (gemm_beside.h), and nobody wants dx of layer 0.
   const int64_t I0 = d->I;
   const bool single = a.data_polls != 0 && P.opt.bwd_single_copy && dx == nullptr && !wg_overlap && B == Bpad &&
-                      (NL == 1 || beside) && (int64_t)T * Bpad * G * 2 < ((int64_t)1 << 31) &&
+                      (NL == 1 || (beside && nch > lag)) && (int64_t)T * Bpad * G * 2 < ((int64_t)1 << 31) &&
                       gemm_tn_takes_blocked_a(G, H, TB, P.opt) && gemm_tn_takes_blocked_a(G, I0, TB, P.opt);
   a.single_copy = single_copy = single ? 1 : 0;
   P.dgates_copies = single ? 1 : 2;
@@ -1078,6 +1078,17 @@ static int backward_persist(Plan& P, char* ws, const float* dy_last,
       lay[ns] = l;
       chk[ns] = c;
       ++ns;
+    }
+    if (ns == 0) {
+      // a diagonal without a layer in range (one chunk per layer, T <= chunk, and the layers two launches apart): nothing
+      // to recur over, but the input-gradient GEMMs the previous launch left for "the next launch" still have to run
+      for (int i = 0; i < npending; ++i) {
+        const BesideGemm& g = pending[i];
+        if (g.a_blocked) return fail(CSN_ERR_UNSUPPORTED, "backward_persist: fragment-major dgates without a launch to carry their GEMM");
+        if ((rc = gemm_nt(g.A, g.Bt, g.bias, g.C, g.M, g.N, g.K, CSN_BF16, CSN_F32, 0, st, P.opt))) return rc;
+      }
+      npending = 0;
+      continue;
     }
     a.nslots = ns;
     a.ngemm = npending;

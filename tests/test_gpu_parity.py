@@ -480,6 +480,33 @@ def _run_lstm(p, x, dy_all, dy_last, C, H, L, dtype, cuda, env=None, want_dx=Tru
                 os.environ[k] = v
 
 
+@pytest.mark.parametrize("B,T,C,H,L", [(1, 1, 8, 128, 1), (2, 2, 8, 128, 2), (3, 3, 16, 256, 2), (1, 5, 128, 768, 2),
+                                       (65, 7, 128, 768, 2), (64, 1, 128, 768, 2), (256, 2, 128, 768, 2),
+                                       (7, 3, 128, 1024, 2), (64, 4, 32, 512, 3), (129, 5, 16, 384, 4),
+                                       (32, 20, 128, 768, 2), (16, 33, 16, 128, 2), (48, 31, 32, 256, 4)])
+def test_short_sequences_and_tiny_batches(cuda, B, T, C, H, L):
+    """Edge shapes at the DEFAULT chunk length (32): sequences shorter than one chunk, shorter than the hand-off ring
+    (T < 4), one row, one step, a second chunk of one step.  With T <= chunk and two or more layers the backward's
+    chunk diagonals (layers two launches apart) include one WITHOUT any layer in range, which must still run the
+    input-gradient GEMM the launch before left for it (a status-1 error before round 3's last fix)."""
+    rng = np.random.default_rng(B * T + H)
+    p = lstm.init_params(C, H, L, 8, None, seed=5)
+    lp = {k[len("lstm."):]: v for k, v in p.items() if k.startswith("lstm.")}
+    x = rng.standard_normal((B, T, C)).astype(np.float32)
+    dy_all = (rng.standard_normal((B, T, H)) * 0.1).astype(np.float32)
+    dy_last = rng.standard_normal((B, H)).astype(np.float32)
+    y, saved = lstm.lstm_forward(x, lp, L, return_saved=True)
+    dy = dy_all.astype(np.float64).copy()
+    dy[:, -1] += dy_last
+    dx_ref, g_ref = lstm.lstm_backward(dy, lp, saved, L)
+    for dt, tol in ((torch.bfloat16, 1.5e-2), (torch.float32, 1e-5)):
+        out = _run_lstm(p, x, dy_all, dy_last, C, H, L, dt, cuda)
+        assert all(np.isfinite(v).all() for v in out.values())
+        assert _rel(out["y_all"], y) < tol and _rel(out["dx"], dx_ref) < tol, (dt, _rel(out["y_all"], y), _rel(out["dx"], dx_ref))
+        for n, gref in g_ref.items():
+            assert _rel(out[n], gref) < tol, (dt, n, _rel(out[n], gref))
+
+
 def _assert_same_bits(a, b, what):
     """Exact equality with a diagnosis of WHERE the arrays differ (a stale hand-off shows up as a block of rows /
     units at one timestep, a summation-order difference as scattered single ulps)."""
