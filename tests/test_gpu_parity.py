@@ -669,6 +669,18 @@ def test_handoff_forms_agree_in_poisoned_workspaces(cuda):
     assert not bad, bad
 
 
+def test_entry_points_on_random_odd_shapes(cuda):
+    """tools/fuzz_entry_points.py: every stateless entry point of the C ABI (band-pass + z-score, filtfilt, both GEMMs in
+    both dtypes, cosine loss, RMSprop step, Barlow reduction, L2 top-k) on seeded random shapes that are NOT multiples of
+    any tile -- one row, one channel, 139 channels, K = 1, prime sizes -- against numpy / scipy / torch in float64."""
+    import subprocess
+    import sys
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_entry_points.py"), "10"],
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert out.stdout.count("\nok ") + out.stdout.startswith("ok ") >= 100, out.stdout[-2000:]
+
+
 def test_ring_slots_never_serve_a_stale_step(cuda):
     """The hand-off by data reuses four slab addresses per layer, so a consumer must never be served the PREVIOUS occupant
     of a slot -- data, which the sentinel proof cannot tell from the right step.  The debug library `make tags`
