@@ -681,6 +681,17 @@ def test_entry_points_on_random_odd_shapes(cuda):
     assert out.stdout.count("\nok ") + out.stdout.startswith("ok ") >= 100, out.stdout[-2000:]
 
 
+def test_lstm_plans_on_random_shapes(cuda):
+    """tools/fuzz_lstm.py: 40 seeded random plans -- both dtypes, 1-4 layers, batch / length / channel counts that are not
+    multiples of any tile, hidden sizes on and off the weight-stationary list, chunk lengths 1..64 (T <= chunk and T >> chunk),
+    with and without per-step output gradients and dx -- against the float64 oracle (bf16 2e-2, f32 2e-5 of the norm)."""
+    import subprocess
+    import sys
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_lstm.py"), "40", "12"],
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+
+
 def test_ring_slots_never_serve_a_stale_step(cuda):
     """The hand-off by data reuses four slab addresses per layer, so a consumer must never be served the PREVIOUS occupant
     of a slot -- data, which the sentinel proof cannot tell from the right step.  The debug library `make tags`
