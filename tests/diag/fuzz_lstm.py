@@ -1,6 +1,6 @@
 """Randomised LSTM plans (both dtypes, 1-4 layers, odd batch / length / channel counts, hidden sizes on and off the
 weight-stationary list, chunk lengths, with and without per-step output gradients and dx) against the float64 oracle.
-A bug hunt: one line per case, exit code 1 on a failure.      python tools/fuzz_lstm.py [cases] [seed]"""
+A bug hunt: one line per case, exit code 1 on a failure.      python tests/diag/fuzz_lstm.py [cases] [seed]"""
 import os
 import sys
 import traceback
@@ -8,7 +8,7 @@ import traceback
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from oracle import lstm      # noqa: E402  (tools/ and tests/ may use the oracle; the product never does)

@@ -682,12 +682,12 @@ def test_entry_points_on_random_odd_shapes(cuda):
 
 
 def test_lstm_plans_on_random_shapes(cuda):
-    """tools/fuzz_lstm.py: 40 seeded random plans -- both dtypes, 1-4 layers, batch / length / channel counts that are not
+    """tests/diag/fuzz_lstm.py: 40 seeded random plans -- both dtypes, 1-4 layers, batch / length / channel counts that are not
     multiples of any tile, hidden sizes on and off the weight-stationary list, chunk lengths 1..64 (T <= chunk and T >> chunk),
     with and without per-step output gradients and dx -- against the float64 oracle (bf16 2e-2, f32 2e-5 of the norm)."""
     import subprocess
     import sys
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_lstm.py"), "40", "12"],
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "diag", "fuzz_lstm.py"), "40", "12"],
                          capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
 
