@@ -82,7 +82,7 @@ def fixture_parity(tag, device):
         feat = m(x)
         loss = CosineSimilarityLoss()(feat, tg)
         loss.backward()
-        check_device_status(m)
+        check_device_status(m, collective=False)      # (rank 0 alone runs this: no collective here)
         gn = float(m.lstm.weight_hh_l0.grad.double().norm())
         out[name] = {"loss": float(loss.item()), "abs_err_vs_f64": abs(float(loss.item()) - float(g["loss_f64"])),
                      "feat_max_abs_err": float(np.abs(feat.detach().cpu().numpy()[:B8] - g["feat_f64"]).max()),

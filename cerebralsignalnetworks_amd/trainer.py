@@ -138,12 +138,14 @@ def shard_indices(n, epoch, seed, rank, world, shuffle=True, device="cpu"):
     return idx[rank:total:world].to(device)
 
 
-def check_device_status(model):
+def check_device_status(model, collective=True):
     """Blocking: raises if an in-kernel hand-off of a weight-stationary LSTM kernel timed out, or a non-finite gradient
     reached the backward recurrence, in ANY forward / backward of ``model`` since the last check (the status word is
     sticky).  Call it at epoch ends / after a timed region / after an evaluation pass, not per step.  Cleared once
     reported.  With torch.distributed initialised the verdict is all-reduced (MAX) first, so every rank raises together
-    instead of one rank leaving the others in the next collective."""
+    instead of one rank leaving the others in the next collective -- which makes the call itself a COLLECTIVE: every
+    rank must reach it.  ``collective=False``: this rank's verdict only (work that one rank does alone, e.g. rank 0's
+    fixture check before a benchmark's timed region)."""
     from . import cabi
     from .lstm_model import HipLSTM
     torch.cuda.synchronize()
@@ -155,7 +157,7 @@ def check_device_status(model):
                 bad |= plan.status(clear=True)
                 dev = plan.device
     _, world = dist_info()
-    if world > 1:
+    if world > 1 and collective:
         on_gpu = dist.get_backend() == "nccl"
         t = torch.tensor([bad & 1, (bad >> 1) & 1, (bad >> 2) & 1], dtype=torch.int32,
                          device=(dev if dev is not None else torch.device("cuda", torch.cuda.current_device())) if on_gpu else "cpu")

@@ -681,6 +681,27 @@ def test_entry_points_on_random_odd_shapes(cuda):
     assert out.stdout.count("\nok ") + out.stdout.startswith("ok ") >= 100, out.stdout[-2000:]
 
 
+def test_bench_two_ranks_rehearsal_on_one_device(cuda):
+    """`python bench.py --gpus 2` end to end -- launcher, rank processes, rank 0's fixture check before the timed region,
+    all-reduced steps, the collective status verdict, the data-parallel proof in the line -- rehearsed on ONE device
+    (CSN_SINGLE_DEVICE: both ranks on GPU 0, gloo instead of RCCL, per-step launches instead of the weight-stationary
+    kernels, which need all of a GPU's CUs to themselves).  Every collective must be reached by every rank: a status
+    check that all-reduced its verdict inside rank 0's solo fixture check broke exactly this run once."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, CSN_SINGLE_DEVICE="1", CSN_DIST_BACKEND="gloo", CSN_NO_PERSIST="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                          "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    dp = res["data_parallel"]
+    assert res["n_gpus"] == 2 and dp["ranks_seen"] == 2 and dp["param_checksum_equal_on_all_ranks"] and dp["single_device_rehearsal"]
+    assert res["parity"]["f32_within_1e-4"] and res["config"]["global_batch"] == 512
+
+
 def test_lstm_plans_on_random_shapes(cuda):
     """tests/diag/fuzz_lstm.py: 40 seeded random plans -- both dtypes, 1-4 layers, batch / length / channel counts that are not
     multiples of any tile, hidden sizes on and off the weight-stationary list, chunk lengths 1..64 (T <= chunk and T >> chunk),
