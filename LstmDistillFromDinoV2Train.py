@@ -114,9 +114,15 @@ def init_distributed():
         sys.exit(1)
     if "RANK" in os.environ and "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) > 1:
         local = int(os.environ.get("LOCAL_RANK", 0))
+        if os.environ.get("CSN_SINGLE_DEVICE"):      # rehearsal of the multi-rank path on a one-GPU box (as in bench.py)
+            local = 0
         torch.cuda.set_device(local)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        backend = os.environ.get("CSN_DIST_BACKEND", "nccl")     # "nccl" is RCCL on ROCm; gloo only for rehearsals
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend=backend)
         return dist.get_rank(), dist.get_world_size(), local
     torch.cuda.set_device(0)
     return 0, 1, 0

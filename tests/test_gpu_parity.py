@@ -702,6 +702,26 @@ def test_bench_two_ranks_rehearsal_on_one_device(cuda):
     assert res["parity"]["f32_within_1e-4"] and res["config"]["global_batch"] == 512
 
 
+def test_train_cli_two_ranks_rehearsal_on_one_device(cuda, tmp_path):
+    """The training CLI under `torch.distributed.run` with two ranks (rehearsal switches as in the bench test: one device,
+    gloo, per-step launches): sharded batches, the flat-buffer gradient all-reduce every step, the collective status
+    verdict per epoch, validation + rank-0 evaluation and checkpoint, barrier + teardown -- no rank may be left in a
+    collective the other never reaches (exit code 0 within the timeout)."""
+    import subprocess
+    import sys
+    env = dict(os.environ, CSN_SINGLE_DEVICE="1", CSN_DIST_BACKEND="gloo", CSN_NO_PERSIST="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29613", os.path.join(ROOT, "LstmDistillFromDinoV2Train.py"),
+                          "--synthetic", "250", "--batch_size", "16", "--num_epochs", "3", "--validation_frequency", "1",
+                          "--log_dir", str(tmp_path), "--hidden_size", "128", "--lstm_layers", "2", "--loss", "cosine"],
+                         env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    assert "EPOCH 2 train_loss" in out.stdout and "val_loss" in out.stdout
+    assert os.path.exists(os.path.join(str(tmp_path), "lstm_dinov2_best_loss.pth"))
+
+
 def test_lstm_plans_on_random_shapes(cuda):
     """tests/diag/fuzz_lstm.py: 40 seeded random plans -- both dtypes, 1-4 layers, batch / length / channel counts that are not
     multiples of any tile, hidden sizes on and off the weight-stationary list, chunk lengths 1..64 (T <= chunk and T >> chunk),
