@@ -722,6 +722,17 @@ def test_train_cli_two_ranks_rehearsal_on_one_device(cuda, tmp_path):
     assert os.path.exists(os.path.join(str(tmp_path), "lstm_dinov2_best_loss.pth"))
 
 
+def test_lstm_usage_patterns(cuda):
+    """tests/diag/usage_patterns.py: inference plans (no_grad), a non-default stream, two forwards of different batch sizes
+    awaiting one backward, repeated calls bit-equal, batches of 512 / 1024 rows (off the weight-stationary path) -- both
+    dtypes, against the float64 oracle."""
+    import subprocess
+    import sys
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "diag", "usage_patterns.py")],
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+
+
 def test_lstm_plans_on_random_shapes(cuda):
     """tests/diag/fuzz_lstm.py: 40 seeded random plans -- both dtypes, 1-4 layers, batch / length / channel counts that are not
     multiples of any tile, hidden sizes on and off the weight-stationary list, chunk lengths 1..64 (T <= chunk and T >> chunk),
