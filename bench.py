@@ -353,6 +353,12 @@ def main():
                 flops_per_launch += (L - 1) * 2.0 * T * B * 4 * H * H / n_l
                 bytes_per_launch += (L - 1) * T * B * (4 * H * 2.0 + H * 4.0) / n_l
             t_launch = us[dom] * 1e-6
+            if t_launch <= 0.0:
+                # (the per-step float32 path records no launch events: its line is the headline's `f32_path` companion)
+                res["roofline"] = None
+                res["roofline_note"] = "no per-launch timing on this path (per-step cell kernels); see profiles/ and DESIGN.md section 6"
+                t_launch = None
+        if not args.no_kernel_timing and t_launch is not None:
             ach_tf = flops_per_launch / t_launch / 1e12
             ach_gb = bytes_per_launch / t_launch / 1e9
             # the binding roofline is the one with the larger minimum time
