@@ -22,3 +22,7 @@ A = torch.randn(8192, 8192, device=dev).to(torch.bfloat16); B = torch.randn(8192
 bench("hipblaslt nn 8192^3", lambda: torch.mm(A, B), 2.0*8192**3)
 bench("hipblaslt nt 8192^3", lambda: torch.mm(A, B.t()), 2.0*8192**3)
 bench("hipblaslt tn 8192^3", lambda: torch.mm(A.t(), B), 2.0*8192**3)
+try:
+    bench("hipblaslt nt 8192x3072x768 f32 out", lambda: torch.mm(a2, b2.t(), out_dtype=torch.float32), 2.0*8192*3072*768)
+except Exception as e:      # noqa: BLE001
+    print("mm(out_dtype=float32) not available:", str(e)[:120])
