@@ -48,7 +48,7 @@ int fail(int status, const char* fmt, ...);
 // library keeps no mutable global state, so plans on different streams / threads / devices never share any.
 struct Options {
   bool cell_v1, no_persist, no_persist_bwd, persist_streams, no_xcd_local, no_rotate, no_fuse_x, no_beside,
-      no_side_stream, gemm_slot, fwd_ksplit, fwd_nsplit, fwd_halves, fwd_ws, fwd_flags, bwd_flags, dpoll_no_hint, fwd_hint, beside_fwd, xproj_bf16, wgrad_overlap, gemm_no_dma, gemm_no_256, gemm_generic, gemm_lds64, tn_no_tr, tn_no_stagger, filter_v1, tags_no_rearm, bwd_single_copy;
+      no_side_stream, gemm_slot, fwd_ksplit, fwd_nsplit, fwd_halves, fwd_ws, fwd_flags, bwd_flags, dpoll_no_hint, fwd_hint, beside_fwd, xproj_bf16, wgrad_overlap, gemm_no_dma, gemm_no_256, gemm_generic, gemm_lds64, tn_no_tr, tn_no_stagger, filter_v1, tags_no_rearm, bwd_single_copy, gemm_no_192;
   int chunk;       // timesteps per weight-stationary launch
   int tn_stages;   // LDS-DMA ring depth of the 256 x 256 weight-gradient kernel
   int fwd_nk;
@@ -87,6 +87,7 @@ static inline Options options_from_env() {
   o.tn_no_stagger = on("CSN_TN_NO_STAGGER");
   o.gemm_no_dma = on("CSN_GEMM_NO_DMA");
   o.gemm_no_256 = on("CSN_GEMM_NO_256");
+  o.gemm_no_192 = on("CSN_GEMM_NO_192");
   o.gemm_generic = on("CSN_GEMM_GENERIC");
   o.gemm_lds64 = on("CSN_GEMM_LDS64");
   o.tn_no_tr = on("CSN_TN_NO_TR");

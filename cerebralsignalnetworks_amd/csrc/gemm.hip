@@ -781,6 +781,127 @@ gemm_nt_256_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ Bt, 
   }   // tile loop
 }
 
+// NT, 256 x 192 output tile (N % 192 == 0): the same kernel with a wider tile -- at the LSTM's chunk shape (8192 x 3072 x 768)
+// 512 tiles = exactly two per CU instead of three, 352 instead of 445 MB through the L2 -> CU fabric, which is what the
+// 256 x 128 form is bound by (the vendor library's 192 x 256 kernel is faster by exactly that ratio).
+// 8 waves (4 along M x 2 along N, 64 x 96 outputs per wave).  A stage of 64 contraction columns is 32 KB of A + 24 KB of
+// B, three of which do not fit the 160 KB of LDS: A keeps a ring of THREE stages (two k-steps ahead: the streaming operand),
+// B a ring of TWO (one k-step ahead: 295 KB per column tile, read by 16 workgroups at a time, L2-resident).  144 KB.
+template <typename OutT>
+__global__ void __launch_bounds__(512)
+gemm_nt_192_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ Bt, const float* __restrict__ bias,
+                   OutT* __restrict__ C, int64_t M, int64_t N, int64_t K, int accumulate) {
+  extern __shared__ __attribute__((aligned(1024))) char smem[];  // A: 3 x 32 KB, then B: 2 x 24 KB
+  constexpr unsigned kBBase = 3 * 32768, kBStage = 24576;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const unsigned ntn = (unsigned)(N / 192);
+  const unsigned ntiles = ntn * (unsigned)((M + 255) / 256);
+  const int nk = (int)(K / 64);
+  for (unsigned lid = xcd_remap(blockIdx.x, gridDim.x); lid < ntiles; lid += gridDim.x) {
+  const int64_t m0 = (int64_t)(lid / ntn) * 256, n0 = (int64_t)(lid % ntn) * 192;
+  __syncthreads();     // every wave has left the previous tile's last stage
+
+  // staging as in gemm_nt_256_kernel: a 1 KB instruction fills 8 rows x 8 chunks, chunk c of LDS row r <- global chunk
+  // c ^ ((r >> 1) & 7); A has 32 instructions per stage (4 per wave), B 24 (3 per wave)
+  const bf16_t* a_src[4];
+  const bf16_t* b_src[3];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = (8 * i + wave) * 8 + (lane >> 3);
+    const int ch = (lane & 7) ^ ((row >> 1) & 7);
+    int64_t am = m0 + row;
+    am = am < M ? am : M - 1;
+    a_src[i] = A + am * K + ch * 8;
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int row = (8 * i + wave) * 8 + (lane >> 3);
+    const int ch = (lane & 7) ^ ((row >> 1) & 7);
+    b_src[i] = Bt + (n0 + row) * K + ch * 8;
+  }
+  auto issue_a = [&](int kt) {
+    char* a_s = smem + (kt % 3) * 32768;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) glds16(a_src[i] + (int64_t)kt * 64, a_s + (8 * i + wave) * 1024);
+  };
+  auto issue_b = [&](int kt) {
+    char* b_s = smem + kBBase + (kt % 2) * kBStage;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) glds16(b_src[i] + (int64_t)kt * 64, b_s + (8 * i + wave) * 1024);
+  };
+
+  const unsigned sw = (unsigned)((lane & 15) >> 1);
+  const unsigned a_base = (unsigned)((wm * 64 + (lane & 15)) * 128) + ((((unsigned)lane >> 4) ^ sw) << 4);
+  const unsigned b_base = kBBase + (unsigned)((wn * 96 + (lane & 15)) * 128) + ((((unsigned)lane >> 4) ^ sw) << 4);
+
+  f32x4 acc[4][6];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 6; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // issue order: A(0) B(0) A(1) | step kt: B(kt+1) A(kt+2).  Behind B(kt) the wave has issued only A(kt+1) (4 pieces):
+  // vmcnt(4) = "A(kt) and B(kt) have landed" (vector-memory operations retire in order)
+  issue_a(0);
+  issue_b(0);
+  if (nk > 1) issue_a(1);
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();      // everybody's pieces of step kt are there; everybody has left step kt - 1
+    if (kt + 1 < nk) issue_b(kt + 1);  // (slot of B(kt-1))
+    if (kt + 2 < nk) issue_a(kt + 2);  // (slot of A(kt-1))
+    const unsigned sa = (unsigned)(kt % 3) * 32768u, sb = (unsigned)(kt % 2) * kBStage;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const unsigned xo = kk ? 64u : 0u;
+      bf16x8 af[4], bfr[6];
+#pragma unroll
+      for (int j = 0; j < 6; ++j) bfr[j] = lds_read_b128(((b_base ^ xo) + sb) + j * 2048u);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[i] = lds_read_b128(((a_base ^ xo) + sa) + i * 2048u);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (i == 0) asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
+        else if (i == 1) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+        else if (i == 2) asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory");
+        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+
+  // epilogue from the accumulators: lane holds row m = .. + (lane & 15), columns n .. n + 3 (a store instruction covers 16
+  // rows x 64 bytes)
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int64_t m = m0 + wm * 64 + i * 16 + (lane & 15);
+    if (m >= M) continue;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const int64_t n = n0 + wn * 96 + j * 16 + (lane >> 4) * 4;
+      f32x4 v = acc[i][j];
+      if (bias) v += *reinterpret_cast<const f32x4*>(bias + n);
+#if defined(CSN_NT_ABL) && CSN_NT_ABL == 1     // (ablation, timing only: no C stores unless a value is NaN)
+      if (v[0] == v[0]) continue;
+#endif
+      if constexpr (sizeof(OutT) == 4) {
+        f32x4* dst = reinterpret_cast<f32x4*>((float*)C + m * N + n);
+        if (accumulate) v += *dst;
+        *dst = v;
+      } else {
+        *reinterpret_cast<bf16x4*>((bf16_t*)C + m * N + n) = (bf16x4){(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+      }
+    }
+  }
+  }   // tile loop
+}
+
 // TN, 256 x 256 output tile, 8 waves (2 along M x 4 along N, 128 x 64 outputs per wave), LDS-DMA stages of
 // 32 k-rows: per 64 contraction rows a workgroup moves 64 KB for 8.4 MFLOP -- half the L2 bytes per flop of the
 // 128 x 128 tiles, whose ceiling is the aggregate L2 bandwidth (~14 TB/s measured => ~0.9 PFLOP/s).
@@ -1068,6 +1189,21 @@ int gemm_nt(const void* A, const void* Bt, const float* bias, void* C, int64_t M
     return launch_generic(A, K, 1, Bt, 1, K, bias, C, N, M, N, K, dtype, out_dtype, accumulate, 1, 0, st);
   // 256 x 128 tiles where the tile count still fills the chip a few times over (measured at the LSTM's chunk
   // shapes: 58 vs 67 us at N = 3072, 56 vs 51 us at N = 768)
+  if (K % 64 == 0 && K >= 256 && M >= 256 && N % 192 == 0 && (N / 192) * ((M + 255) / 256) >= 256 && !opt.gemm_no_dma &&
+      !opt.gemm_no_256 && !opt.gemm_no_192) {
+    // 256 x 192 tiles where they still give every CU a tile: 21 % fewer operand bytes per flop than 256 x 128 (measured at
+    // 8192 x 3072 x 768: 53.2 vs 59.0 us, 39.4 vs 47.2 without the C stores; at 8192 x 768 x 3072 -- 128 tiles -- 66 vs 47)
+    constexpr int kLds192 = 3 * 32768 + 2 * 24576;
+    if (int rc = ensure_dyn_lds<&gemm_nt_192_kernel<bf16_t>>(kLds192)) return rc;
+    if (int rc = ensure_dyn_lds<&gemm_nt_192_kernel<float>>(kLds192)) return rc;
+    dim3 grid192((unsigned)((N / 192) * ((M + 255) / 256)));
+    if (out_dtype == CSN_BF16)
+      gemm_nt_192_kernel<bf16_t><<<grid192, 512, kLds192, st>>>((const bf16_t*)A, (const bf16_t*)Bt, bias, (bf16_t*)C, M, N, K, 0);
+    else
+      gemm_nt_192_kernel<float><<<grid192, 512, kLds192, st>>>((const bf16_t*)A, (const bf16_t*)Bt, bias, (float*)C, M, N, K, accumulate);
+    CSN_LAUNCH_CHECK();
+    return CSN_OK;
+  }
   if (K % 64 == 0 && K >= 256 && M >= 256 && N >= 1024 && !opt.gemm_no_dma && !opt.gemm_no_256) {
     if (int rc = ensure_dyn_lds<&gemm_nt_256_kernel<bf16_t, 3>>(3 * 49152)) return rc;
     if (int rc = ensure_dyn_lds<&gemm_nt_256_kernel<float, 3>>(3 * 49152)) return rc;

@@ -669,6 +669,31 @@ def test_handoff_forms_agree_in_poisoned_workspaces(cuda):
     assert not bad, bad
 
 
+@pytest.mark.parametrize("M,N,K", [(8192, 3072, 768), (300, 24960, 128), (513, 12480, 192), (4096, 3072, 64)])
+def test_gemm_nt_wide_tile_kernel(cuda, M, N, K):
+    """csn_gemm_nt's 256 x 192 tile kernel (N % 192 == 0 and at least one tile per CU): same k order as the 256 x 128 kernel,
+    so the float32 output must be BIT-equal to it (CSN_GEMM_NO_192 selects the old kernel); rows that do not fill the last
+    tile, bias, accumulate and bfloat16 output against float64."""
+    g = torch.Generator(device=cuda).manual_seed(M + N + K)
+    a = torch.randn(M, K, device=cuda, generator=g).to(torch.bfloat16)
+    b = torch.randn(N, K, device=cuda, generator=g).to(torch.bfloat16)
+    bias = torch.randn(N, device=cuda, generator=g)
+    ref = a.double() @ b.double().t() + bias.double()
+    out = cabi.gemm_nt(a, b, bias)
+    assert float((out.double() - ref).norm() / ref.norm()) < 2e-6
+    os.environ["CSN_GEMM_NO_192"] = "1"
+    try:
+        old = cabi.gemm_nt(a, b, bias)
+    finally:
+        del os.environ["CSN_GEMM_NO_192"]
+    assert torch.equal(out, old)
+    o16 = cabi.gemm_nt(a, b, bias, out_dtype=torch.bfloat16)
+    assert float((o16.double() - ref).norm() / ref.norm()) < 4e-3
+    acc = out.clone()
+    cabi.gemm_nt(a, b, None, out=acc, accumulate=True)
+    assert float((acc.double() - (2 * ref - bias.double())).norm() / ref.norm()) < 4e-6
+
+
 def test_entry_points_on_random_odd_shapes(cuda):
     """tools/fuzz_entry_points.py: every stateless entry point of the C ABI (band-pass + z-score, filtfilt, both GEMMs in
     both dtypes, cosine loss, RMSprop step, Barlow reduction, L2 top-k) on seeded random shapes that are NOT multiples of
