@@ -53,9 +53,12 @@ struct WsLayout {
 static WsLayout make_layout(const csnLstmDesc& d, int training, const Options& opt) {
   WsLayout w{};
   w.il = cell_blk_supported(d.H, d.dtype, opt);
+  // (the K-split weight-stationary kernels address their per-step hand-off slabs with 32-bit byte offsets from step 0: a
+  // sequence whose slabs reach 4 GiB takes the per-diagonal launches; the N-split kernel bases its resources per launch)
+  const bool slabs_fit = ((size_t)d.T + 1) * (((size_t)d.B + 63) / 64 * 64) * (size_t)d.H * 8 < ((size_t)1 << 32);
   w.fwd_ns = w.il && fwd_ns_supported(d.B, d.H, d.dtype, opt) && d.L <= 4;
-  w.persist = w.fwd_ns || (w.il && fwd_persist_supported(d.B, d.H, d.dtype, opt) && d.L <= 4);
-  w.persist_bwd = w.persist && training && bwd_persist_supported(d.B, d.H, d.dtype, opt);
+  w.persist = w.fwd_ns || (w.il && slabs_fit && fwd_persist_supported(d.B, d.H, d.dtype, opt) && d.L <= 4);
+  w.persist_bwd = w.persist && slabs_fit && training && bwd_persist_supported(d.B, d.H, d.dtype, opt);
   size_t off = 0;
   const size_t es = dtype_size(d.dtype);
   auto take = [&](size_t bytes) {

@@ -149,23 +149,26 @@ __device__ __forceinline__ void ns_recurrence(const PersistFwdArgs& a, const Per
   f32x4 nxt[P];
   const bool xbf = !FUSED && __builtin_amdgcn_readfirstlane(S.xproj_bf16) != 0;
   const unsigned xslab = FUSED ? (unsigned)a.Bpad * (unsigned)S.I : 0u;
-  const __amdgpu_buffer_rsrc_t in_rsrc = FUSED
-      ? __builtin_amdgcn_make_buffer_rsrc((void*)ns_uniform(S.x_blk), 0, __builtin_amdgcn_readfirstlane((int)((size_t)a.T * xslab * 2)), 0x00020000)
-      : __builtin_amdgcn_make_buffer_rsrc((void*)ns_uniform(S.xproj), 0, __builtin_amdgcn_readfirstlane((int)((size_t)a.T * B * 16 * H)), 0x00020000);
+  // Buffer resources are based at THIS LAUNCH's first step and sized for its steps: byte offsets inside them are 32-bit
+  // (the float32 projection is 4 MB per step at B = 256, H = 1024 -- 4 GiB, where offsets from step 0 wrapped, at T = 1024)
+  const size_t in_step_bytes = FUSED ? (size_t)xslab * 2 : (size_t)B * H * (xbf ? 8 : 16);
+  const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)ns_uniform((FUSED ? (const char*)S.x_blk : (const char*)S.xproj) + (size_t)t_first * in_step_bytes), 0,
+      __builtin_amdgcn_readfirstlane((int)((size_t)nsteps * in_step_bytes)), 0x00020000);
   int xvoff[4];                                            // plain: byte offset of (row, first unit) inside a step's [B, 4H] f32 slab
 #pragma unroll
   for (int rg = 0; rg < 4; ++rg) xvoff[rg] = (int)(((size_t)rowc[rg] * 4 * H + 4 * (size_t)unit_q) * 4);
   auto request_input = [&](int t) {
     if constexpr (FUSED) {
       // the 64 rows x 128 features of x_t are 16 contiguous 1 KB fragment blocks: one base, constant offsets
-      const int sbase = __builtin_amdgcn_readfirstlane((int)(((size_t)t * xslab + (size_t)(m0 >> 4) * xkb * 512) * 2));
+      const int sbase = __builtin_amdgcn_readfirstlane((int)(((size_t)(t - t_first) * xslab + (size_t)(m0 >> 4) * xkb * 512) * 2));
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg)
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) nxt[rg * 4 + kb] = ns_bload_nt_f32x4(in_rsrc, lane * 16 + (rg * 4 + kb) * 1024, sbase);
     } else if (xbf) {
       // bf16 projection: 8 bytes per cell, widened on arrival
-      const int sbase = __builtin_amdgcn_readfirstlane((int)((size_t)t * B * 8 * H));
+      const int sbase = __builtin_amdgcn_readfirstlane((int)((size_t)(t - t_first) * B * 8 * H));
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg)
 #pragma unroll
@@ -175,7 +178,7 @@ __device__ __forceinline__ void ns_recurrence(const PersistFwdArgs& a, const Per
                                     __builtin_bit_cast(float, v[1] << 16), __builtin_bit_cast(float, v[1] & 0xffff0000u)};
         }
     } else {
-      const int sbase = __builtin_amdgcn_readfirstlane((int)((size_t)t * B * 16 * H));
+      const int sbase = __builtin_amdgcn_readfirstlane((int)((size_t)(t - t_first) * B * 16 * H));
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg)
 #pragma unroll
@@ -184,8 +187,9 @@ __device__ __forceinline__ void ns_recurrence(const PersistFwdArgs& a, const Per
   };
   request_input(t_first);
 
-  const __amdgpu_buffer_rsrc_t hdst_rsrc =
-      __builtin_amdgcn_make_buffer_rsrc((void*)ns_uniform(S.h_blk_all), 0, __builtin_amdgcn_readfirstlane((int)((size_t)(a.T + 1) * slab * 2)), 0x00020000);
+  const __amdgpu_buffer_rsrc_t hdst_rsrc =        // (slabs t_first .. t_first + nsteps: read h_{t-1} from slab t, write h_t to slab t + 1)
+      __builtin_amdgcn_make_buffer_rsrc((void*)ns_uniform(S.h_blk_all + (size_t)t_first * slab), 0,
+                                        __builtin_amdgcn_readfirstlane((int)((size_t)(nsteps + 1) * slab * 2)), 0x00020000);
 
   for (int s = 0; s < nsteps; ++s) {
     const int t = t_first + s;
@@ -209,7 +213,7 @@ __device__ __forceinline__ void ns_recurrence(const PersistFwdArgs& a, const Per
     constexpr int SB = KB >= 32 ? 1 : 2;                     // groups in flight (register budget)
     bf16x8 stg[SB][GI];
     int kb_next = rot;                                       // k-block of walk position p, kept as a running scalar
-    const int sbase = __builtin_amdgcn_readfirstlane((int)(((size_t)t * slab + (size_t)((m0 >> 4) + wave) * KB * 512) * 2));
+    const int sbase = __builtin_amdgcn_readfirstlane((int)(((size_t)(t - t_first) * slab + (size_t)((m0 >> 4) + wave) * KB * 512) * 2));
     auto issue_group = [&](int buf) {
 #if defined(CSN_NS_ABL) && CSN_NS_ABL >= 1
       return;                                               // ablation (timing only): no h loads
@@ -352,7 +356,7 @@ __device__ __forceinline__ void ns_recurrence(const PersistFwdArgs& a, const Per
       {
         const int rg = tid >> 6, r15 = tid & 15, q = (tid >> 4) & 3;
         const nu32x4 v = *reinterpret_cast<const nu32x4*>(sh + (rg * 16 + r15) * 80 + q * 16);
-        const unsigned hoff = (unsigned)(((size_t)(t + 1) * slab + ((size_t)((m0 >> 4) + rg) * KB + slice) * 512) * 2) + (unsigned)(tid & 63) * 16u;
+        const unsigned hoff = (unsigned)(((size_t)(t + 1 - t_first) * slab + ((size_t)((m0 >> 4) + rg) * KB + slice) * 512) * 2) + (unsigned)(tid & 63) * 16u;
         if (local) ns_store_b128<false>(hdst_rsrc, hoff, v);
         else ns_store_b128<true>(hdst_rsrc, hoff, v);
       }

@@ -747,6 +747,18 @@ def test_train_cli_two_ranks_rehearsal_on_one_device(cuda, tmp_path):
     assert os.path.exists(os.path.join(str(tmp_path), "lstm_dinov2_best_loss.pth"))
 
 
+def test_long_sequences_beyond_4gib_offsets(cuda):
+    """tests/diag/long_sequence.py at T = 1100: at B = 256, H = 1024 the float32 input projection is 4 MB per step, and the
+    N-split forward kernel addressed it with a 32-bit byte offset from step 0 -- garbage from step 1024 on (relative
+    difference 1.0), silently.  Its buffer resources are based per launch now; the K-split kernels leave sequences whose
+    slabs reach 4 GiB to the per-diagonal launches.  Outputs per step and the weight gradients against those launches."""
+    import subprocess
+    import sys
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "diag", "long_sequence.py"), "1100"],
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+
+
 def test_lstm_usage_patterns(cuda):
     """tests/diag/usage_patterns.py: inference plans (no_grad), a non-default stream, two forwards of different batch sizes
     awaiting one backward, repeated calls bit-equal, batches of 512 / 1024 rows (off the weight-stationary path) -- both
