@@ -781,31 +781,35 @@ gemm_nt_256_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ Bt, 
   }   // tile loop
 }
 
-// NT, 256 x 192 output tile (N % 192 == 0): the same kernel with a wider tile -- at the LSTM's chunk shape (8192 x 3072 x 768)
-// 512 tiles = exactly two per CU instead of three, 352 instead of 445 MB through the L2 -> CU fabric, which is what the
-// 256 x 128 form is bound by (the vendor library's 192 x 256 kernel is faster by exactly that ratio).
-// 8 waves (4 along M x 2 along N, 64 x 96 outputs per wave).  A stage of 64 contraction columns is 32 KB of A + 24 KB of
-// B, three of which do not fit the 160 KB of LDS: A keeps a ring of THREE stages (two k-steps ahead: the streaming operand),
-// B a ring of TWO (one k-step ahead: 295 KB per column tile, read by 16 workgroups at a time, L2-resident).  144 KB.
-template <typename OutT>
+// NT, 256 x BN output tile, BN = 192 or 256 (N % BN == 0): the same kernel with a wider tile -- at the LSTM's chunk shapes
+// (8192 x 3072 x 768 with BN = 192, 8192 x 4096 x 1024 with BN = 256) 512 tiles = exactly two per CU instead of three /
+// four, 21 % / 33 % fewer bytes through the L2 -> CU fabric, which is what the 256 x 128 form is bound by (DESIGN.md
+// section 6: the vendor library's 192 x 256 kernel is faster by exactly that ratio).  8 waves (4 along M x 2 along N,
+// 64 x BN/2 outputs per wave).  A stage of 64 contraction columns is 32 KB of A + 24 / 32 KB of B, three of which do not
+// fit the 160 KB of LDS: A keeps a ring of THREE stages (two k-steps ahead: the streaming operand), B a ring of TWO (one
+// k-step ahead: a few hundred KB per column tile, read by 16 workgroups at a time, L2-resident).  144 / 160 KB.
+template <typename OutT, int BN>
 __global__ void __launch_bounds__(512)
-gemm_nt_192_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ Bt, const float* __restrict__ bias,
+gemm_nt_wide_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ Bt, const float* __restrict__ bias,
                    OutT* __restrict__ C, int64_t M, int64_t N, int64_t K, int accumulate) {
-  extern __shared__ __attribute__((aligned(1024))) char smem[];  // A: 3 x 32 KB, then B: 2 x 24 KB
-  constexpr unsigned kBBase = 3 * 32768, kBStage = 24576;
+  static_assert(BN == 192 || BN == 256, "column tile");
+  extern __shared__ __attribute__((aligned(1024))) char smem[];  // A: 3 x 32 KB, then B: 2 x (24 | 32) KB
+  constexpr unsigned kBBase = 3 * 32768, kBStage = BN * 128;
+  constexpr int NBI = BN / 64;       // B staging instructions per wave and stage
+  constexpr int NBF = BN / 32;       // B fragments (16 columns each) per wave
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const unsigned ntn = (unsigned)(N / 192);
+  const unsigned ntn = (unsigned)(N / BN);
   const unsigned ntiles = ntn * (unsigned)((M + 255) / 256);
   const int nk = (int)(K / 64);
   for (unsigned lid = xcd_remap(blockIdx.x, gridDim.x); lid < ntiles; lid += gridDim.x) {
-  const int64_t m0 = (int64_t)(lid / ntn) * 256, n0 = (int64_t)(lid % ntn) * 192;
+  const int64_t m0 = (int64_t)(lid / ntn) * 256, n0 = (int64_t)(lid % ntn) * BN;
   __syncthreads();     // every wave has left the previous tile's last stage
 
   // staging as in gemm_nt_256_kernel: a 1 KB instruction fills 8 rows x 8 chunks, chunk c of LDS row r <- global chunk
-  // c ^ ((r >> 1) & 7); A has 32 instructions per stage (4 per wave), B 24 (3 per wave)
+  // c ^ ((r >> 1) & 7); A has 32 instructions per stage (4 per wave), B 24 / 32 (3 / 4 per wave)
   const bf16_t* a_src[4];
-  const bf16_t* b_src[3];
+  const bf16_t* b_src[NBI];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int row = (8 * i + wave) * 8 + (lane >> 3);
@@ -815,7 +819,7 @@ gemm_nt_192_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ Bt, 
     a_src[i] = A + am * K + ch * 8;
   }
 #pragma unroll
-  for (int i = 0; i < 3; ++i) {
+  for (int i = 0; i < NBI; ++i) {
     const int row = (8 * i + wave) * 8 + (lane >> 3);
     const int ch = (lane & 7) ^ ((row >> 1) & 7);
     b_src[i] = Bt + (n0 + row) * K + ch * 8;
@@ -828,18 +832,18 @@ gemm_nt_192_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ Bt, 
   auto issue_b = [&](int kt) {
     char* b_s = smem + kBBase + (kt % 2) * kBStage;
 #pragma unroll
-    for (int i = 0; i < 3; ++i) glds16(b_src[i] + (int64_t)kt * 64, b_s + (8 * i + wave) * 1024);
+    for (int i = 0; i < NBI; ++i) glds16(b_src[i] + (int64_t)kt * 64, b_s + (8 * i + wave) * 1024);
   };
 
   const unsigned sw = (unsigned)((lane & 15) >> 1);
   const unsigned a_base = (unsigned)((wm * 64 + (lane & 15)) * 128) + ((((unsigned)lane >> 4) ^ sw) << 4);
-  const unsigned b_base = kBBase + (unsigned)((wn * 96 + (lane & 15)) * 128) + ((((unsigned)lane >> 4) ^ sw) << 4);
+  const unsigned b_base = kBBase + (unsigned)((wn * (BN / 2) + (lane & 15)) * 128) + ((((unsigned)lane >> 4) ^ sw) << 4);
 
-  f32x4 acc[4][6];
+  f32x4 acc[4][NBF];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 6; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NBF; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   // issue order: A(0) B(0) A(1) | step kt: B(kt+1) A(kt+2).  Behind B(kt) the wave has issued only A(kt+1) (4 pieces):
   // vmcnt(4) = "A(kt) and B(kt) have landed" (vector-memory operations retire in order)
@@ -856,9 +860,9 @@ gemm_nt_192_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ Bt, 
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       const unsigned xo = kk ? 64u : 0u;
-      bf16x8 af[4], bfr[6];
+      bf16x8 af[4], bfr[NBF];
 #pragma unroll
-      for (int j = 0; j < 6; ++j) bfr[j] = lds_read_b128(((b_base ^ xo) + sb) + j * 2048u);
+      for (int j = 0; j < NBF; ++j) bfr[j] = lds_read_b128(((b_base ^ xo) + sb) + j * 2048u);
 #pragma unroll
       for (int i = 0; i < 4; ++i) af[i] = lds_read_b128(((a_base ^ xo) + sa) + i * 2048u);
 #pragma unroll
@@ -869,7 +873,7 @@ gemm_nt_192_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ Bt, 
         else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int j = 0; j < 6; ++j)
+        for (int j = 0; j < NBF; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -883,8 +887,8 @@ gemm_nt_192_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ Bt, 
     const int64_t m = m0 + wm * 64 + i * 16 + (lane & 15);
     if (m >= M) continue;
 #pragma unroll
-    for (int j = 0; j < 6; ++j) {
-      const int64_t n = n0 + wn * 96 + j * 16 + (lane >> 4) * 4;
+    for (int j = 0; j < NBF; ++j) {
+      const int64_t n = n0 + wn * (BN / 2) + j * 16 + (lane >> 4) * 4;
       f32x4 v = acc[i][j];
       if (bias) v += *reinterpret_cast<const f32x4*>(bias + n);
 #if defined(CSN_NT_ABL) && CSN_NT_ABL == 1     // (ablation, timing only: no C stores unless a value is NaN)
@@ -1189,20 +1193,37 @@ int gemm_nt(const void* A, const void* Bt, const float* bias, void* C, int64_t M
     return launch_generic(A, K, 1, Bt, 1, K, bias, C, N, M, N, K, dtype, out_dtype, accumulate, 1, 0, st);
   // 256 x 128 tiles where the tile count still fills the chip a few times over (measured at the LSTM's chunk
   // shapes: 58 vs 67 us at N = 3072, 56 vs 51 us at N = 768)
-  if (K % 64 == 0 && K >= 256 && M >= 256 && N % 192 == 0 && (N / 192) * ((M + 255) / 256) >= 256 && !opt.gemm_no_dma &&
-      !opt.gemm_no_256 && !opt.gemm_no_192) {
-    // 256 x 192 tiles where they still give every CU a tile: 21 % fewer operand bytes per flop than 256 x 128 (measured at
-    // 8192 x 3072 x 768: 53.2 vs 59.0 us, 39.4 vs 47.2 without the C stores; at 8192 x 768 x 3072 -- 128 tiles -- 66 vs 47)
-    constexpr int kLds192 = 3 * 32768 + 2 * 24576;
-    if (int rc = ensure_dyn_lds<&gemm_nt_192_kernel<bf16_t>>(kLds192)) return rc;
-    if (int rc = ensure_dyn_lds<&gemm_nt_192_kernel<float>>(kLds192)) return rc;
-    dim3 grid192((unsigned)((N / 192) * ((M + 255) / 256)));
-    if (out_dtype == CSN_BF16)
-      gemm_nt_192_kernel<bf16_t><<<grid192, 512, kLds192, st>>>((const bf16_t*)A, (const bf16_t*)Bt, bias, (bf16_t*)C, M, N, K, 0);
-    else
-      gemm_nt_192_kernel<float><<<grid192, 512, kLds192, st>>>((const bf16_t*)A, (const bf16_t*)Bt, bias, (float*)C, M, N, K, accumulate);
-    CSN_LAUNCH_CHECK();
-    return CSN_OK;
+  if (K % 64 == 0 && K >= 256 && M >= 256 && !opt.gemm_no_dma && !opt.gemm_no_256 && !opt.gemm_no_192) {
+    // 256 x 256 or 256 x 192 tiles where they give every CU whole tiles: 33 % / 21 % fewer operand bytes per flop than
+    // 256 x 128 (measured at 8192 x 3072 x 768: 53.2 vs 59.0 us, 39.4 vs 47.2 without the C stores; at 8192 x 768 x 3072
+    // -- 128 tiles of 192 -- 66 vs 47: hence "at least one tile per CU, and at most 10 % of the last round empty")
+    auto fills = [&](int bn) {
+      if (N % bn != 0) return false;
+      const int64_t t = (N / bn) * ((M + 255) / 256), rounds = (t + 255) / 256;
+      return t >= 256 && t * 10 >= rounds * 256 * 9;
+    };
+    const int bn = fills(256) ? 256 : (fills(192) ? 192 : 0);
+    if (bn != 0) {
+      const int lds = 3 * 32768 + 2 * bn * 128;
+      dim3 gridw((unsigned)((N / bn) * ((M + 255) / 256)));
+      if (bn == 256) {
+        if (int rc = ensure_dyn_lds<&gemm_nt_wide_kernel<bf16_t, 256>>(lds)) return rc;
+        if (int rc = ensure_dyn_lds<&gemm_nt_wide_kernel<float, 256>>(lds)) return rc;
+        if (out_dtype == CSN_BF16)
+          gemm_nt_wide_kernel<bf16_t, 256><<<gridw, 512, lds, st>>>((const bf16_t*)A, (const bf16_t*)Bt, bias, (bf16_t*)C, M, N, K, 0);
+        else
+          gemm_nt_wide_kernel<float, 256><<<gridw, 512, lds, st>>>((const bf16_t*)A, (const bf16_t*)Bt, bias, (float*)C, M, N, K, accumulate);
+      } else {
+        if (int rc = ensure_dyn_lds<&gemm_nt_wide_kernel<bf16_t, 192>>(lds)) return rc;
+        if (int rc = ensure_dyn_lds<&gemm_nt_wide_kernel<float, 192>>(lds)) return rc;
+        if (out_dtype == CSN_BF16)
+          gemm_nt_wide_kernel<bf16_t, 192><<<gridw, 512, lds, st>>>((const bf16_t*)A, (const bf16_t*)Bt, bias, (bf16_t*)C, M, N, K, 0);
+        else
+          gemm_nt_wide_kernel<float, 192><<<gridw, 512, lds, st>>>((const bf16_t*)A, (const bf16_t*)Bt, bias, (float*)C, M, N, K, accumulate);
+      }
+      CSN_LAUNCH_CHECK();
+      return CSN_OK;
+    }
   }
   if (K % 64 == 0 && K >= 256 && M >= 256 && N >= 1024 && !opt.gemm_no_dma && !opt.gemm_no_256) {
     if (int rc = ensure_dyn_lds<&gemm_nt_256_kernel<bf16_t, 3>>(3 * 49152)) return rc;

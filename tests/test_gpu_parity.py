@@ -669,9 +669,10 @@ def test_handoff_forms_agree_in_poisoned_workspaces(cuda):
     assert not bad, bad
 
 
-@pytest.mark.parametrize("M,N,K", [(8192, 3072, 768), (300, 24960, 128), (513, 12480, 192), (4096, 3072, 64)])
+@pytest.mark.parametrize("M,N,K", [(8192, 3072, 768), (300, 24960, 128), (513, 12480, 192), (4096, 3072, 64),
+                                   (8192, 4096, 1024), (500, 32768, 128), (2048, 8192, 320)])      # (the last three: 256 x 256 tiles)
 def test_gemm_nt_wide_tile_kernel(cuda, M, N, K):
-    """csn_gemm_nt's 256 x 192 tile kernel (N % 192 == 0 and at least one tile per CU): same k order as the 256 x 128 kernel,
+    """csn_gemm_nt's 256 x 192 / 256 x 256 tile kernel (N % 192 or % 256 == 0, whole rounds of tiles over the CUs): same k order as the 256 x 128 kernel,
     so the float32 output must be BIT-equal to it (CSN_GEMM_NO_192 selects the old kernel); rows that do not fill the last
     tile, bias, accumulate and bfloat16 output against float64."""
     g = torch.Generator(device=cuda).manual_seed(M + N + K)

@@ -4,7 +4,7 @@ from cerebralsignalnetworks_amd import cabi
 dev = torch.device("cuda:0")
 g = torch.Generator(device=dev).manual_seed(1)
 def rnd(*s): return torch.randn(*s, device=dev, generator=g)
-for (M, N, K) in ((8192, 3072, 768), (8192, 768, 3072), (300, 960, 256), (256, 768, 256), (1000, 1152, 448), (257, 1920, 320)):
+for (M, N, K) in ((8192, 3072, 768), (8192, 4096, 1024), (8192, 768, 3072), (300, 960, 256), (500, 32768, 128), (257, 1920, 320)):
     a, b = rnd(M, K).to(torch.bfloat16), rnd(N, K).to(torch.bfloat16)
     bias = rnd(N)
     ref = a.double() @ b.double().t() + bias.double()
@@ -42,3 +42,9 @@ out3 = torch.empty(8192, 768, device=dev)
 bench("nt 8192x768x3072 f32 (256x192)", lambda: cabi.gemm_nt(a3, b3, None, out=out3), 2.0 * 8192 * 3072 * 768)
 os.environ["CSN_GEMM_NO_192"] = "1"
 bench("nt 8192x768x3072 f32 (old)", lambda: cabi.gemm_nt(a3, b3, None, out=out3), 2.0 * 8192 * 3072 * 768)
+del os.environ["CSN_GEMM_NO_192"]
+a4, b4 = rnd(8192, 1024).to(torch.bfloat16), rnd(4096, 1024).to(torch.bfloat16)
+bias4 = rnd(4096); out4 = torch.empty(8192, 4096, device=dev)
+bench("nt 8192x4096x1024 f32 (256x256)", lambda: cabi.gemm_nt(a4, b4, bias4, out=out4), 2.0 * 8192 * 4096 * 1024)
+os.environ["CSN_GEMM_NO_192"] = "1"
+bench("nt 8192x4096x1024 f32 (256x128)", lambda: cabi.gemm_nt(a4, b4, bias4, out=out4), 2.0 * 8192 * 4096 * 1024)
