@@ -1193,7 +1193,7 @@ int gemm_nt(const void* A, const void* Bt, const float* bias, void* C, int64_t M
     return launch_generic(A, K, 1, Bt, 1, K, bias, C, N, M, N, K, dtype, out_dtype, accumulate, 1, 0, st);
   // 256 x 128 tiles where the tile count still fills the chip a few times over (measured at the LSTM's chunk
   // shapes: 58 vs 67 us at N = 3072, 56 vs 51 us at N = 768)
-  if (K % 64 == 0 && K >= 256 && M >= 256 && !opt.gemm_no_dma && !opt.gemm_no_256 && !opt.gemm_no_192) {
+  if (K % 64 == 0 && K >= 128 && M >= 256 && !opt.gemm_no_dma && !opt.gemm_no_256 && !opt.gemm_no_192) {
     // 256 x 256 or 256 x 192 tiles where they give every CU whole tiles: 33 % / 21 % fewer operand bytes per flop than
     // 256 x 128 (measured at 8192 x 3072 x 768: 53.2 vs 59.0 us, 39.4 vs 47.2 without the C stores; at 8192 x 768 x 3072
     // -- 128 tiles of 192 -- 66 vs 47: hence "at least one tile per CU, and at most 10 % of the last round empty")

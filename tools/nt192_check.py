@@ -48,3 +48,12 @@ bias4 = rnd(4096); out4 = torch.empty(8192, 4096, device=dev)
 bench("nt 8192x4096x1024 f32 (256x256)", lambda: cabi.gemm_nt(a4, b4, bias4, out=out4), 2.0 * 8192 * 4096 * 1024)
 os.environ["CSN_GEMM_NO_192"] = "1"
 bench("nt 8192x4096x1024 f32 (256x128)", lambda: cabi.gemm_nt(a4, b4, bias4, out=out4), 2.0 * 8192 * 4096 * 1024)
+del os.environ["CSN_GEMM_NO_192"]
+a5, b5 = rnd(112640, 128).to(torch.bfloat16), rnd(4096, 128).to(torch.bfloat16)
+bias5 = rnd(4096); out5 = torch.empty(112640, 4096, device=dev)
+ref5 = None
+bench("nt 112640x4096x128 f32 (wide)", lambda: cabi.gemm_nt(a5, b5, bias5, out=out5), 2.0 * 112640 * 4096 * 128, reps=10)
+w = out5.clone()
+os.environ["CSN_GEMM_NO_192"] = "1"
+bench("nt 112640x4096x128 f32 (old)", lambda: cabi.gemm_nt(a5, b5, bias5, out=out5), 2.0 * 112640 * 4096 * 128, reps=10)
+print("bit-equal:", bool(torch.equal(w, out5)))
