@@ -119,6 +119,10 @@ __global__ void reduce_slabs_unperm_kernel(const float* __restrict__ slabs, int6
 // layouts.  As separate kernels that was 13 launches of 5-40 us with a dependent-launch gap behind each (0.15 ms of an
 // 11 ms step); here every job gets a slice of one grid.
 __global__ void __launch_bounds__(256) prep_multi_kernel(PrepArgs A) {
+  // (the two TRANSPOSING jobs -- W_ih^T and the fragment-major W_hh^T of the backward -- read down columns of a row-major
+  // float32 matrix: as 4-byte gathers they set the length of this launch (58 us); through a 64 x 64 LDS tile both sides
+  // of the transpose move whole 64 / 256-byte runs)
+  __shared__ __attribute__((aligned(16))) bf16_t tp[64][72];
   int j = 0;
   while (j + 1 < A.njobs && blockIdx.x >= A.job[j + 1].blk_begin) ++j;
   const PrepJob& J = A.job[j];
@@ -128,6 +132,31 @@ __global__ void __launch_bounds__(256) prep_multi_kernel(PrepArgs A) {
     case kPrepBlockify: {                 // fragment-major bf16 image of a (permuted) float32 matrix
       const int64_t R = J.n0, K = J.n1, H = J.H, ld_r = J.s0, ld_k = J.s1, kblocks = K >> 5;
       bf16_t* dst = (bf16_t*)J.dst;
+      if (J.perm_k && !J.perm_r && ld_r == 1 && (R & 63) == 0 && (K & 63) == 0 && (ld_k & 3) == 0) {
+        // element (u, k') = a[std_row(k') * ld_k + u]: tile = 64 units x 64 k'; source rows are contiguous along u
+        const int64_t tiles_u = R >> 6, ntiles = tiles_u * (K >> 6);
+        const int t = threadIdx.x, rr = t >> 2, seg = t & 3;
+        for (int64_t tile = vb; tile < ntiles; tile += vg) {
+          const int64_t tu = tile % tiles_u, tk = tile / tiles_u;
+          const float4* sp = reinterpret_cast<const float4*>(J.a + std_row(tk * 64 + rr, H) * ld_k + tu * 64 + seg * 16);
+          const float4 q0 = sp[0], q1 = sp[1], q2 = sp[2], q3 = sp[3];
+          *reinterpret_cast<bf16x8*>(&tp[rr][seg * 16]) = (bf16x8){(bf16_t)q0.x, (bf16_t)q0.y, (bf16_t)q0.z, (bf16_t)q0.w, (bf16_t)q1.x, (bf16_t)q1.y, (bf16_t)q1.z, (bf16_t)q1.w};
+          *reinterpret_cast<bf16x8*>(&tp[rr][seg * 16 + 8]) = (bf16x8){(bf16_t)q2.x, (bf16_t)q2.y, (bf16_t)q2.z, (bf16_t)q2.w, (bf16_t)q3.x, (bf16_t)q3.y, (bf16_t)q3.z, (bf16_t)q3.w};
+          __syncthreads();
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const int c = t + 256 * h, fb = c >> 6, lane = c & 63, rb = fb >> 1, kb = fb & 1;
+            const int ul = rb * 16 + (lane & 15), kl = kb * 32 + 8 * (lane >> 4);
+            bf16x8 v;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = tp[kl + e][ul];
+            const int64_t blk = (tu * 4 + rb) * kblocks + tk * 2 + kb;
+            *reinterpret_cast<bf16x8*>(dst + (blk * 64 + lane) * 8) = v;
+          }
+          __syncthreads();
+        }
+        break;
+      }
       for (int64_t ci = gid; ci < R * K / 8; ci += stride) {
         const int64_t blk = ci >> 6, lane = ci & 63;
         const int64_t r = (blk / kblocks) * 16 + (lane & 15), k = (blk % kblocks) * 32 + 8 * (lane >> 4);
@@ -167,6 +196,24 @@ __global__ void __launch_bounds__(256) prep_multi_kernel(PrepArgs A) {
     case kPrepTransPerm: {                // dst[i][n'] = src[std_row(n')][i]
       const int64_t H = J.H, I = J.n1, G = 4 * H;
       bf16_t* dst = (bf16_t*)J.dst;
+      if ((I & 63) == 0 && (G & 63) == 0) {
+        const int64_t tiles_n = G >> 6, ntiles = tiles_n * (I >> 6);
+        const int t = threadIdx.x, rr = t >> 2, seg = t & 3;
+        for (int64_t tile = vb; tile < ntiles; tile += vg) {
+          const int64_t tn = tile % tiles_n, ti = tile / tiles_n;
+          const float4* sp = reinterpret_cast<const float4*>(J.a + std_row(tn * 64 + rr, H) * I + ti * 64 + seg * 16);
+          const float4 q0 = sp[0], q1 = sp[1], q2 = sp[2], q3 = sp[3];
+          const float v[16] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
+#pragma unroll
+          for (int e = 0; e < 16; ++e) tp[seg * 16 + e][rr] = (bf16_t)v[e];      // [i][n']
+          __syncthreads();
+          bf16_t* dp = dst + (ti * 64 + rr) * G + tn * 64 + seg * 16;              // rr = i here: 16 consecutive n'
+          *reinterpret_cast<bf16x8*>(dp) = *reinterpret_cast<const bf16x8*>(&tp[rr][seg * 16]);
+          *reinterpret_cast<bf16x8*>(dp + 8) = *reinterpret_cast<const bf16x8*>(&tp[rr][seg * 16 + 8]);
+          __syncthreads();
+        }
+        break;
+      }
       for (int64_t i = gid; i < G * I; i += stride) dst[i] = (bf16_t)J.a[std_row(i % G, H) * I + i / G];
       break;
     }
