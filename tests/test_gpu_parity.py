@@ -760,6 +760,22 @@ def test_long_sequences_beyond_4gib_offsets(cuda):
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
 
 
+def test_rccl_backend_one_rank(cuda):
+    """What one GPU can show of the RCCL path: every collective the bench and the trainer issue (dtypes, reduce ops) on a
+    one-rank "nccl" communicator, and six data-parallel training steps at the benchmark shape with the flat-buffer
+    all-reduce on the device between the weight-stationary launches (tests/diag/rccl_ops_one_rank.py,
+    nccl_trainer_one_rank.py; each in a process of its own)."""
+    import subprocess
+    import sys
+    for script in ("rccl_ops_one_rank.py", "nccl_trainer_one_rank.py"):
+        env = dict(os.environ)
+        for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+            env.pop(k, None)
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "diag", script)], env=env,
+                             capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0 and " ok" in out.stdout, (script, out.stdout[-1500:], out.stderr[-3000:])
+
+
 def test_lstm_usage_patterns(cuda):
     """tests/diag/usage_patterns.py: inference plans (no_grad), a non-default stream, two forwards of different batch sizes
     awaiting one backward, repeated calls bit-equal, batches of 512 / 1024 rows (off the weight-stationary path) -- both
