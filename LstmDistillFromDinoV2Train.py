@@ -106,6 +106,18 @@ class _KdParams:
     temperature = 2.0
 
 
+class _LoaderEmbedder:
+    """What the reference hands to ``dataset.transformEEGDataLSTMByList`` is its model; items of a loader over the dataset
+    are ``eeg[T, C]`` as ``__getitem__`` returns them, so here the callable also applies the step's preprocessing (the
+    fused band-pass + z-score takes the stored channel-first layout)."""
+
+    def __init__(self, trainer):
+        self.trainer = trainer
+
+    def __call__(self, eeg_btc):
+        return self.trainer.model(self.trainer.embed(eeg_btc.transpose(1, 2).contiguous()))
+
+
 def init_distributed():
     """One process per GPU; RCCL when launched by torchrun, single process otherwise
     (utils/utils.py:467-503 exits without a GPU -- so does this)."""
@@ -131,7 +143,8 @@ def init_distributed():
 def main(argv=None, flavour=PERILS):
     from cerebralsignalnetworks_amd import Model, EEGFilters
     from cerebralsignalnetworks_amd.dataset import EEGDataset
-    from cerebralsignalnetworks_amd.retrieval import evaluate_full
+    from cerebralsignalnetworks_amd.retrieval import evaluate_distributed, evaluate_full
+    from torch.utils.data import DataLoader, Subset
     from cerebralsignalnetworks_amd.trainer import DistillTrainer, shard_indices, split_indices
     from cerebralsignalnetworks_amd.losses import HyperParams
 
@@ -201,22 +214,52 @@ def main(argv=None, flavour=PERILS):
         epoch_loss = float(torch.stack(losses).mean().item())                    # one sync per epoch, not per step
         if EPOCH % FLAGS.validation_frequency == 0 and EPOCH > 0:
             model.eval()
-            gallery = trainer.embed_all(dataset.eeg_all[train_idx], FLAGS.batch_size)
-            query = trainer.embed_all(dataset.eeg_all[val_idx], FLAGS.batch_size)
-            vlosses = []
+            if FLAGS.compat_label_bug:
+                # the reference's own retrieval leg, call for call (:383-389): both loaders go through
+                # dataset.transformEEGDataLSTMByList, whose labels are looked up by the position INSIDE the batch
+                # (PerilsEEGDataset.py:336-338) -- Recall / Precision come out as the reference prints them, not as
+                # retrieval quality.  Every rank walks the whole loaders, like the reference's ranks.
+                embedder = _LoaderEmbedder(trainer)
+                loaders = [DataLoader(Subset(dataset, ix.tolist()), batch_size=FLAGS.batch_size, shuffle=False)
+                           for ix in (train_idx, val_idx)]
+                gallery_features, gallery_labels = dataset.transformEEGDataLSTMByList(model=embedder, data_loader=loaders[0])
+                query_features, query_labels = dataset.transformEEGDataLSTMByList(model=embedder, data_loader=loaders[1])
+                r = evaluate_full(FLAGS, gallery_features, query_features, gallery_labels, query_labels, dataset)
+            else:
+                # each rank embeds ITS shard of the gallery and of the queries; the neighbour lists are gathered
+                g_ix = train_idx[shard_indices(len(train_idx), 0, FLAGS.seed, rank, world, shuffle=False).to(device)]
+                q_ix = val_idx[shard_indices(len(val_idx), 0, FLAGS.seed, rank, world, shuffle=False).to(device)]
+                if world > 1:       # (the sampler pads a shard by wrapping around: drop the duplicates again)
+                    g_ix = g_ix[: len(range(rank, len(train_idx), world))]
+                    q_ix = q_ix[: len(range(rank, len(val_idx), world))]
+                gallery = trainer.embed_all(dataset.eeg_all[g_ix], FLAGS.batch_size)
+                query = trainer.embed_all(dataset.eeg_all[q_ix], FLAGS.batch_size)
+                r = evaluate_distributed(FLAGS, list(gallery.cpu().numpy()), list(query.cpu().numpy()), labels_of(g_ix),
+                                         labels_of(q_ix), dataset)
+            # validation loss over ALL ranks' shards: sum of the batch losses and their count, one all-reduce, so that
+            # the best-checkpoint decision below is the same on every rank and covers the whole validation split
+            vsum = torch.zeros(2, device=device, dtype=torch.float64)
             with torch.no_grad():
                 for b in batches(val_idx, 0, False):
                     out = model(trainer.embed(dataset.eeg_all[b]))
-                    vlosses.append(trainer.compute_loss(out, dataset.features_all[b], dataset.labels_dev[b], EPOCH))
-            val_epoch_loss = float(torch.stack(vlosses).mean().item())
+                    vsum[0] += trainer.compute_loss(out, dataset.features_all[b], dataset.labels_dev[b], EPOCH).double()
+                    vsum[1] += 1
+            if world > 1:
+                if dist.get_backend() == "nccl":
+                    dist.all_reduce(vsum)
+                else:                       # gloo rehearsal: host tensors
+                    host = vsum.cpu()
+                    dist.all_reduce(host)
+                    vsum = host
+            val_epoch_loss = float((vsum[0] / vsum[1]).item())
+            improved = best_val_loss is None or val_epoch_loss < best_val_loss
+            if improved:
+                first = best_val_loss is None
+                best_val_loss, best_val_loss_epoch = val_epoch_loss, EPOCH
+                if is_main:
+                    torch.save(model.state_dict(), flavour.checkpoint_path(FLAGS.log_dir, EPOCH, FLAGS.num_epochs, first))
             if is_main:
-                r = evaluate_full(FLAGS, list(gallery.cpu().numpy()), list(query.cpu().numpy()), labels_of(train_idx),
-                                  labels_of(val_idx), dataset)
                 print(f"Overall Recall :{r['Recall_Total']} Overall Precision: {r['Precision_Total']} top1: {r['top1']:.4f}")
-                if best_val_loss is None or val_epoch_loss < best_val_loss:
-                    ckpt = flavour.checkpoint_path(FLAGS.log_dir, EPOCH, FLAGS.num_epochs, best_val_loss is None)
-                    best_val_loss, best_val_loss_epoch = val_epoch_loss, EPOCH
-                    torch.save(model.state_dict(), ckpt)
                 print(f"EPOCH {EPOCH} train_loss: {round(epoch_loss, 6)} val_loss: {round(val_epoch_loss, 6)} "
                       f"T: {HyperParams.T} best val loss: {best_val_loss} on epoch: {best_val_loss_epoch}")
         elif is_main:

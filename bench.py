@@ -26,8 +26,10 @@ sys.path.insert(0, ROOT)
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16, MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
 HBM_PEAK_GBS = 8000.0            # HBM3E spec, same guide
-PMC_TRAFFIC_FILE = "r03_pmc_traffic.json"      # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/pmc_traffic.sh)
-PMC_COUNTERS_FILE = "r03_pmc_counters.json"    # MFMA-busy / wait / L2-hit / LDS-conflict passes (tools/pmc_counters.sh)
+# committed rocprofv3 --pmc passes per workload (tools/pmc_traffic.sh: FETCH_SIZE / WRITE_SIZE; tools/pmc_counters.sh:
+# MFMA-busy / wait / L2-hit / LDS-conflict), each carrying the kernel-source fingerprint it was collected with
+PMC_FILES = {"cfg2": ("r04_pmc_traffic.json", "r04_pmc_counters.json"),
+             "cfg4": ("r04_cfg4_pmc_traffic.json", "r04_cfg4_pmc_counters.json")}
 
 
 def csrc_sha16():
@@ -130,6 +132,11 @@ def launcher_command(n_gpus, argv, port=None):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on these hosts (RCCL needs it)
     env.setdefault("OMP_NUM_THREADS", "4")
+    if env.get("CSN_SINGLE_DEVICE"):
+        # rehearsal: N ranks on ONE device.  A weight-stationary launch needs every CU of the device for itself (one
+        # workgroup per CU, all co-resident): two ranks' launches would wait for each other until the bounded spins give
+        # up -- the per-diagonal launches are the form that can share a device
+        env.setdefault("CSN_NO_PERSIST", "1")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     return cmd, env
@@ -297,7 +304,10 @@ def main():
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
         dp = {"ranks_seen": int(ones.item()), "param_checksum": int(csum.item()),
               "param_checksum_equal_on_all_ranks": bool(lo.item() == hi.item()),
-              "allreduce_ms_per_step": trainer.grads.all_reduce_ms(), "allreduce_bytes": trainer.grads.flat.numel() * 4,
+              "allreduce_exposed_ms_per_step": trainer.grads.all_reduce_ms(),
+              "allreduce_overlapped": trainer.grads.segments is not None,
+              "allreduce_segments_bytes": [4 * (e - s_) for s_, e in (trainer.grads.segments or [(0, trainer.grads.flat.numel())])],
+              "allreduce_bytes": trainer.grads.flat.numel() * 4,
               "backend": dist.get_backend(), "single_device_rehearsal": bool(os.environ.get("CSN_SINGLE_DEVICE"))}
         if dp["ranks_seen"] != args.gpus or not dp["param_checksum_equal_on_all_ranks"]:
             print(f"bench.py: rank {rank}: data-parallel check failed: {dp}", file=sys.stderr)
@@ -325,6 +335,10 @@ def main():
         }
         if dp is not None:
             res["data_parallel"] = dp
+            if dp["single_device_rehearsal"]:
+                # N ranks shared one device: plumbing evidence only, never a throughput number
+                res["rehearsal_value"], res["value"], res["vs_baseline"] = res["value"], None, None
+                res["note"] = "CSN_SINGLE_DEVICE rehearsal: all ranks on one GPU, per-diagonal launches; `value` withheld"
         if parity is not None:
             res["parity"] = parity
         if not args.no_kernel_timing:
@@ -334,9 +348,9 @@ def main():
             peak = MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else 157.3
             us = {k: (1e3 * pr[k + "_ms"] / max(1, pr[k + "_launches"])) for k in ("fwd", "bwd")}
             dom = "bwd" if pr["bwd_ms"] >= pr["fwd_ms"] else "fwd"      # largest total time in the step
-            persist = {k: pr[k + "_launches"] < T for k in ("fwd", "bwd")}     # weight-stationary: one launch per chunk
-            kname = ("lstm_bwd_persist_kernel" if persist["bwd"] else "lstm_cell_bwd_il_kernel") if dom == "bwd" else (
-                "lstm_fwd_persist_kernel" if persist["fwd"] else "lstm_cell_fwd_il_kernel")
+            knames = dict(zip(("fwd", "bwd"), train_plan.kernel_names()))      # from the plan's path (csn_lstm_plan_kernel_name)
+            persist = {k: "persist" in knames[k] or "_ns_" in knames[k] for k in ("fwd", "bwd")}     # weight-stationary: one launch per chunk
+            kname = knames[dom]
             cells_per_launch = pr[dom + "_cells"] / max(1, pr[dom + "_launches"])
             # algorithmic work of one cell problem (one layer, one timestep):
             #   flops: the recurrent product 2 * B * 4H * H
@@ -368,8 +382,10 @@ def main():
             traffic = mfma_util = None
             traffic_source = None
             try:
-                if (B, C, T, H, L) != (256, 128, 500, 768, 2):
-                    raise KeyError("PMC passes were collected for cfg2 only")
+                wl = {(256, 128, 500, 768, 2): "cfg2", (256, 128, 440, 1024, 2): "cfg4"}.get((B, C, T, H, L))
+                if wl is None:
+                    raise KeyError("PMC passes are committed for the cfg2 and cfg4 workloads only")
+                PMC_TRAFFIC_FILE, PMC_COUNTERS_FILE = PMC_FILES[wl]
                 pmc = json.load(open(os.path.join(ROOT, "profiles", PMC_TRAFFIC_FILE)))
                 cnt = json.load(open(os.path.join(ROOT, "profiles", PMC_COUNTERS_FILE)))
                 now = csrc_sha16()

@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("CSN_LIB_PATH") or os.path.join(_HERE, "lib", "libcsn_
 
 CSN_F32, CSN_BF16 = 0, 1
 STATUS_TIMEOUT, STATUS_NONFINITE, STATUS_STALE_SLOT = 1, 2, 4      # bits of csn_lstm_status_read (include/csn_hip.h)
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _c_void_p, _c_int, _c_i64, _c_size_t, _c_float = (ctypes.c_void_p, ctypes.c_int, ctypes.c_int64,
                                                   ctypes.c_size_t, ctypes.c_float)
@@ -41,6 +41,8 @@ SIGNATURES = {
     "csn_lstm_plan_workspace_bytes": (_c_size_t, [_c_void_p]),
     "csn_lstm_plan_path": (_c_int, [_c_void_p]),
     "csn_lstm_plan_dgates_copies": (_c_int, [_c_void_p]),
+    "csn_lstm_plan_kernel_name": (ctypes.c_char_p, [_c_void_p, _c_int]),
+    "csn_lstm_plan_set_grad_callback": (_c_int, [_c_void_p, _c_void_p, _c_void_p]),
     "csn_lstm_workspace_bytes": (_c_size_t, [ctypes.POINTER(LstmDesc), _c_int]),
     "csn_lstm_forward": (_c_int, [_c_void_p, _c_void_p, _c_i64, _c_i64,
                                   ctypes.POINTER(_c_void_p), ctypes.POINTER(_c_void_p),
@@ -74,6 +76,9 @@ SIGNATURES = {
     "csn_l2_topk": (_c_int, [_c_void_p, _c_void_p, _c_i64, _c_i64, _c_int, _c_int, _c_void_p, _c_void_p,
                              _c_void_p, _c_void_p]),
 }
+
+
+GRAD_READY_FN = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_int)      # csnGradReadyFn(user, layer)
 
 
 class CsnError(RuntimeError):
@@ -255,6 +260,18 @@ class LstmPlan:
     def path(self):
         """0 generic cells, 1 per-diagonal bf16 launches, 2 weight-stationary forward, 3 + weight-stationary backward."""
         return load().csn_lstm_plan_path(self._plan)
+
+    def kernel_names(self):
+        """(forward, backward) recurrence kernel of this plan's path, as a rocprofv3 kernel trace names them."""
+        lib = load()
+        return tuple((lib.csn_lstm_plan_kernel_name(self._plan, k) or b"").decode() for k in (0, 1))
+
+    def set_grad_callback(self, fn):
+        """fn(layer) is called on this thread from inside backward() once layer's gradient kernels are enqueued (top layer
+        first); None removes it.  The ctypes thunk is kept alive by the plan."""
+        self._grad_cb = GRAD_READY_FN(lambda _user, layer: fn(int(layer))) if fn is not None else None
+        _check(load().csn_lstm_plan_set_grad_callback(self._plan, ctypes.cast(self._grad_cb, _c_void_p) if fn is not None
+                                                      else None, None))
 
     def dgates_copies(self):
         """Copies of the gate gradients the last backward wrote per step (csn_hip.h): 1, 2, or 0 before any backward."""

@@ -23,6 +23,7 @@
 //              dgates[T,B,4H], dx[T,B,I_l] f32; fast path adds the fragment-major ping-pong
 //              buffers of h and dgates.  In the fast path every 4H axis is gate-interleaved
 //              (n' = 4 unit + gate); parameters and their gradients are (un)permuted at the API.
+#include <algorithm>
 #include <vector>
 
 #include "csn_common.h"
@@ -105,12 +106,12 @@ static WsLayout make_layout(const csnLstmDesc& d, int training, const Options& o
   }
   w.x_c = take(TB * d.I * es);
   w.status = take(256);
-  // (H = 512 excluded: its 64 x 32-unit tile leaves no registers for the W_ih fragments.  N-split kernel: fused up to
-  // H = 768 only -- at H = 1024 W_hh alone fills the 256 AGPRs the stationary operands must live in, and with the 32
-  // registers of W_ih on top the fused instantiation computes wrong row groups (tried in round 3 once it no longer
-  // spilled: copies of one segment in different row groups differ); cfg4 keeps its layer-0 projection as a GEMM)
+  // (H = 512 excluded: its 64 x 32-unit tile leaves no registers for the W_ih fragments.  N-split kernel at H = 1024: W_hh
+  // fills the 256 AGPRs, W_ih's 32 registers are VGPR operands of their MFMAs -- round 3's fused instantiation asked for
+  // AGPRs there too and the compiler's copies ran into an MFMA read hazard the recogniser cannot see inside inline asm
+  // (wrong row group 0; tools/check_asm_hazards.py).  CSN_NO_FUSE_X keeps the projection GEMM.)
   w.fuse_x = w.persist && !opt.no_fuse_x &&
-             (w.fwd_ns ? (d.I == 128 && d.H <= 768) : (d.I % 32 == 0 && d.I <= 128 && d.H != 512));
+             (w.fwd_ns ? d.I == 128 : (d.I % 32 == 0 && d.I <= 128 && d.H != 512));
   if (w.fuse_x) {
     w.x_blk = take((size_t)d.T * Bpad * d.I * 2);
     w.wih0_blk = take(G * d.I * 2);
@@ -282,6 +283,11 @@ struct csnLstmPlan {
   csn::SideCtx sc;
   csn::Prof prof;
   int dgates_copies = 0;      // what the last backward wrote per step (csn_lstm_plan_dgates_copies)
+  csnGradReadyFn grad_cb = nullptr;      // csn_lstm_plan_set_grad_callback
+  void* grad_cb_user = nullptr;
+  void grads_ready(int layer) const {
+    if (grad_cb != nullptr) grad_cb(grad_cb_user, layer);
+  }
 };
 
 using namespace csn;
@@ -298,6 +304,14 @@ extern "C" int csn_lstm_plan_create(const csnLstmDesc* d, int training, csnLstmP
     return fail(CSN_ERR_HIP, "csn_lstm_plan_create: hipGetDevice failed");
   }
   P->opt = options_from_env();
+  {
+    // the weight-stationary kernels address the steps of ONE launch with 32-bit byte offsets from the launch's base
+    // (lstm_fwd_ns.hip; launch_fwd_ns refuses more): a CSN_LSTM_CHUNK that large is clamped here, not left to wrap
+    const unsigned long long Bp = ((unsigned long long)d->B + 63) / 64 * 64;
+    const unsigned long long per_step = std::max({(unsigned long long)d->B * d->H * 16ull, Bp * (unsigned long long)d->I * 2ull, Bp * (unsigned long long)d->H * 2ull});
+    const unsigned long long cmax = ((1ull << 32) - 1ull) / per_step;
+    if (cmax >= 3 && (unsigned long long)P->opt.chunk > cmax - 2) P->opt.chunk = (int)(cmax - 2);
+  }
   P->w = make_layout(*d, P->training, P->opt);
   *out = P;
   return CSN_OK;
@@ -328,6 +342,38 @@ extern "C" int csn_lstm_plan_path(const csnLstmPlan* P) {
 }
 
 extern "C" int csn_lstm_plan_dgates_copies(const csnLstmPlan* P) { return P == nullptr ? -1 : P->dgates_copies; }
+
+// does the backward of this plan take the grouped weight-stationary form (backward_il's dispatch)?
+static bool bwd_grouped(const csnLstmPlan* P) {
+  if (!P->w.persist_bwd) return false;
+  const int MTg = (P->d.B + 63) / 64, nchg = (P->d.T + P->opt.chunk - 1) / P->opt.chunk;
+  const int slots = P->d.L < nchg ? P->d.L : nchg;
+  return slots <= 4 && slots * MTg <= 8 && !P->opt.persist_streams;
+}
+
+extern "C" const char* csn_lstm_plan_kernel_name(const csnLstmPlan* P, int which) {
+  if (P == nullptr) return nullptr;
+  const bool ks = (P->d.dtype == CSN_F32 ? P->d.H % 128 == 0 : P->d.H % 256 == 0);      // K-split cell kernels (lstm_cell.hip)
+  if (which == 0) {
+    if (P->w.fwd_ns) return P->opt.fwd_ws && P->d.H == 768 ? "lstm_fwd_ws_kernel" : "lstm_fwd_ns_kernel";
+    if (P->w.persist) return "lstm_fwd_persist_kernel";
+    if (P->w.il) return "lstm_cell_fwd_il_kernel";
+    return ks ? "lstm_cell_fwd_ks_kernel" : "lstm_cell_fwd_kernel";
+  }
+  if (which == 1) {
+    if (bwd_grouped(P)) return "lstm_bwd_persist_kernel";
+    if (P->w.il) return "lstm_cell_bwd_il_kernel";
+    return ks ? "lstm_cell_bwd_ks_kernel" : "lstm_cell_bwd_kernel";
+  }
+  return nullptr;
+}
+
+extern "C" int csn_lstm_plan_set_grad_callback(csnLstmPlan* P, csnGradReadyFn fn, void* user) {
+  CSN_REQUIRE(P != nullptr, "csn_lstm_plan_set_grad_callback: null plan");
+  P->grad_cb = fn;
+  P->grad_cb_user = fn ? user : nullptr;
+  return CSN_OK;
+}
 
 extern "C" int csn_lstm_profile_enable(csnLstmPlan* P, int on) {
   CSN_REQUIRE(P != nullptr, "csn_lstm_profile_enable: null plan");
@@ -501,6 +547,7 @@ static int backward_v1(Plan& P, char* ws, const float* dy_last, const float* dy_
     if ((rc = gemm_tn_full(ws + L.dgates, inp, dw_ih[l], G, I, TB, dt, ws + w.tn_scratch, st, P.opt))) return rc;
     if ((rc = launch_colsum(ws + L.dgates, TB, G, dt, db_ih[l], ws + w.colsum, st))) return rc;
     CSN_HIP_CHECK(hipMemcpyAsync(db_hh[l], db_ih[l], (size_t)G * 4, hipMemcpyDeviceToDevice, st));
+    P.grads_ready(l);
     if (l > 0 || dx) {
       if ((rc = gemm_nt(ws + L.dgates, ws + L.wiht, nullptr, ws + L.dx, TB, I, G, dt, CSN_F32, 0, st, P.opt)))
         return rc;
@@ -829,12 +876,7 @@ static int backward_il(Plan& P, char* ws, const float* dy_last, const float* dy_
   const WsLayout& w = P.w;
   Prof& g_prof = P.prof;
   hipStream_t st = as_stream(stream);
-  if (w.persist_bwd) {
-    const int MTg = (d->B + 63) / 64, nchg = (d->T + P.opt.chunk - 1) / P.opt.chunk;
-    const int slots = d->L < nchg ? d->L : nchg;
-    if (slots <= 4 && slots * MTg <= 8 && !P.opt.persist_streams)
-      return backward_persist(P, ws, dy_last, dy_tm, dw_ih, dw_hh, db_ih, db_hh, dx, st);
-  }
+  if (bwd_grouped(&P)) return backward_persist(P, ws, dy_last, dy_tm, dw_ih, dw_hh, db_ih, db_hh, dx, st);
   SideCtx* sc = &P.sc;
   int rc;
   if ((rc = side_ctx(P.sc))) return rc;
@@ -951,7 +993,10 @@ static int backward_il(Plan& P, char* ws, const float* dy_last, const float* dy_
   g_prof.launches[1] = n_launch;
   g_prof.cells[1] = n_cells;
   g_prof.have[1] = g_prof.on;
-  return hand_off(sc, side, st);   // the caller's stream resumes after all side-stream work
+  if ((rc = hand_off(sc, side, st))) return rc;   // the caller's stream resumes after all side-stream work
+  // (the weight gradients of this path run on the side stream: only now are they ordered before the caller's stream)
+  for (int l = NL - 1; l >= 0; --l) P.grads_ready(l);
+  return CSN_OK;
 }
 
 // Weight-stationary backward recurrence (lstm_bwd_persist.hip), grouped form: ONE launch per chunk diagonal
@@ -1141,9 +1186,17 @@ static int backward_persist(Plan& P, char* ws, const float* dy_last,
     tb_to_bt_kernel<<<grid_for(TB * d->I), 256, 0, st>>>((const float*)(ws + L.dx), dx, B, T, d->I);
     CSN_LAUNCH_CHECK();
   }
-  for (int l = NL - 1; l >= 0; --l)
-    if (!wg_done[l] && (rc = weight_grads(l, st, w.tn_scratch, w.colsum))) return rc;
-  if (wg_side && (rc = hand_off(&P.sc, P.sc.wgrad, st))) return rc;     // the caller's stream resumes after the side work
+  // (every recurrence launch has been enqueued by now: what a gradient-ready callback starts -- a collective on another
+  // stream -- runs beside the remaining layers' weight-gradient GEMMs, never beside a one-workgroup-per-CU launch)
+  for (int l = NL - 1; l >= 0; --l) {
+    if (wg_done[l]) continue;
+    if ((rc = weight_grads(l, st, w.tn_scratch, w.colsum))) return rc;
+    if (!wg_side) P.grads_ready(l);
+  }
+  if (wg_side) {
+    if ((rc = hand_off(&P.sc, P.sc.wgrad, st))) return rc;     // the caller's stream resumes after the side work
+    for (int l = NL - 1; l >= 0; --l) P.grads_ready(l);
+  }
   return CSN_OK;
 }
 

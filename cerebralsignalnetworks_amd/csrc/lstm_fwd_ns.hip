@@ -28,6 +28,8 @@
 //
 // 32 units per workgroup: H/32 workgroups per hand-off group (24 at H = 768, leaving 8 CUs per XCD to the layer-1
 // input-projection GEMM carried by the launch, see gemm_beside.h; 32 at H = 1024).
+#include <algorithm>
+
 #include "csn_common.h"
 #include "lstm_cell_common.h"
 #include "lstm_cell_blk.h"
@@ -251,7 +253,7 @@ __device__ __forceinline__ void ns_recurrence(const PersistFwdArgs& a, const Per
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg)
 #pragma unroll
-          for (int j = 0; j < 2; ++j) ns_mfma<AIA>(acc[rg][j], wih[kb][j], __builtin_bit_cast(bf16x8, nxt[rg * 4 + kb]));
+          for (int j = 0; j < 2; ++j) ns_mfma<AIA, !AIA>(acc[rg][j], wih[kb][j], __builtin_bit_cast(bf16x8, nxt[rg * 4 + kb]));
       __builtin_amdgcn_sched_barrier(0);
       CSN_NSTAMP(9);   // x MFMAs
     } else {
@@ -550,6 +552,15 @@ int launch_fwd_ns(const PersistFwdArgs& a, hipStream_t st) {
   for (int i = 0; i < a.nslots; ++i) {
     fused = fused || a.slot[i].x_blk != nullptr;
     CSN_REQUIRE(a.slot[i].x_blk == nullptr || a.slot[i].I == 128, "launch_fwd_ns: the fused input projection takes I = 128");
+    // the kernel's buffer resources are based at the launch's first step and addressed with 32-bit byte offsets: the
+    // steps of ONE launch (CSN_LSTM_CHUNK) must keep the float32 projection ([B, 4H] per step), the fragment-major input
+    // ([Bpad, I] bf16) and the h slabs ([Bpad, H] bf16, nsteps + 1 of them) below 4 GiB each
+    const unsigned long long n = (unsigned long long)a.slot[i].nsteps;
+    const unsigned long long worst = std::max({n * (unsigned long long)a.B * a.H * 16ull,
+                                               n * (unsigned long long)a.Bpad * (unsigned long long)a.slot[i].I * 2ull,
+                                               (n + 1ull) * (unsigned long long)a.Bpad * a.H * 2ull});
+    CSN_REQUIRE(worst < (1ull << 32), "launch_fwd_ns: %llu steps per launch at B=%d H=%d address %llu bytes from the launch's base "
+                "(32-bit offsets): lower CSN_LSTM_CHUNK", n, a.B, a.H, worst);
   }
 #ifdef CSN_EXPERIMENTS
   if (a.H == 768) return fused ? launch_ns_t<24, true, true>(a, st) : launch_ns_t<24, false, true>(a, st);
@@ -562,9 +573,7 @@ int launch_fwd_ns(const PersistFwdArgs& a, hipStream_t st) {
     CSN_NS_CASE(8);
     CSN_NS_CASE(12);
     CSN_NS_CASE(16);
-    case 1024:      // (no fused instantiation at H = 1024: see the plan's fuse_x in lstm.hip)
-      CSN_REQUIRE(!fused, "launch_fwd_ns: the fused layer-0 projection exists up to H = 768");
-      return launch_ns_t<32, false, false>(a, st);
+    CSN_NS_CASE(32);      // (H = 1024, fused: W_ih in VGPRs -- lstm_ns_util.h:ns_mfma<.., WV>)
   }
 #undef CSN_NS_CASE
   return fail(CSN_ERR_UNSUPPORTED, "launch_fwd_ns: no kernel for H=%d", a.H);

@@ -35,10 +35,25 @@ __device__ __forceinline__ bf16x8 ns_lds_read_b128(unsigned addr) {
 // cycles per MFMA instead of 16 (in-kernel stamps with the loads and the LDS reads ablated: unchanged).  CDNA3/4 MFMAs
 // read A/B operands from AGPRs directly, so the weights simply LIVE there.  AIA: the accumulator is in AGPRs too
 // (H <= 768: 8 * 24 + 32 + 32 <= 256); at H = 1024 the weights alone fill the 256 AGPRs and it stays in VGPRs.
-template <bool AIA>
+// WV: this stationary operand lives in VGPRs (the fused layer 0 at H = 1024: W_hh fills all 256 AGPRs, so the 32 registers
+// of W_ih must NOT carry an "a" constraint -- with one, the compiler kept 8 W_hh fragments in VGPRs and copied each into
+// a[32:39] straight in front of its first MFMA; the hazard recogniser does not see an MFMA inside an asm block, so no
+// wait state separated `v_accvgpr_write_b32 a35, ...` from the MFMA reading a[32:35]: row group 0 of every tile
+// multiplied stale dwords.  tools/check_asm_hazards.py fails the build on that pattern)
+template <bool AIA, bool WV = false>
 __device__ __forceinline__ void ns_mfma(f32x4& acc, const bf16x8& w, const bf16x8& h) {
+#if defined(CSN_NS_HAZARD_DEMO)      // `make hazard_demo` (never shipped): round 3's form for the A/B of DESIGN.md section 3.8 --
+  constexpr bool wv = false;        // every stationary operand asks for the accumulator file again
+#else
+  constexpr bool wv = WV;
+#endif
   if constexpr (AIA) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "a"(w), "v"(h));
+  else if constexpr (wv) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(w), "v"(h));
+#if defined(CSN_NS_HAZARD_DEMO) && CSN_NS_HAZARD_DEMO == 2      // ... plus the two wait states the recogniser would have inserted
+  else asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "a"(w), "v"(h));
+#else
   else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "a"(w), "v"(h));
+#endif
 }
 // (the hazard recogniser does not see inside inline asm: explicit wait states where a VALU result feeds the first MFMA
 // of a phase, and where the last MFMA's result is read back -- 16-pass MFMA: up to 18 wait states)

@@ -43,6 +43,7 @@ class _LstmFunction(torch.autograd.Function):
         plan = owner._checkout(x.shape[0], x.shape[1], x.device, training)
         y_last, y_all = plan.forward(x, w_ih, w_hh, b_ih, b_hh, want_all=want_all)
         ctx.lease, ctx.L, ctx.want_all = _Lease(plan), L, want_all
+        ctx.owner = owner
         ctx.need_dx = x.requires_grad
         ctx.x_shape = x.shape
         ctx.param_like = params
@@ -58,10 +59,22 @@ class _LstmFunction(torch.autograd.Function):
         if plan is None:
             raise RuntimeError("HipLSTM: second backward through one forward -- its workspace was handed back after the "
                                "first (retain_graph / double backward are not supported)")
-        grads = [[torch.empty_like(p) for p in ctx.param_like[g * L:(g + 1) * L]] for g in range(4)]
+        owner = ctx.owner
+        direct = owner.direct_grads and all(p.grad is not None and p.grad.is_contiguous() and p.grad.dtype == torch.float32
+                                            for p in ctx.param_like)
+        if direct:
+            # the library OVERWRITES its gradient outputs: written straight into the parameters' .grad (the views into the
+            # trainer's flat buffer) this forward's contribution needs no temporaries and no accumulation pass -- valid
+            # while this is the only forward of the step that uses these parameters (the trainer's contract)
+            grads = [[p.grad for p in ctx.param_like[g * L:(g + 1) * L]] for g in range(4)]
+        else:
+            grads = [[torch.empty_like(p) for p in ctx.param_like[g * L:(g + 1) * L]] for g in range(4)]
         dx = torch.empty(ctx.x_shape, dtype=torch.float32, device=dy_last.device) if ctx.need_dx else None
+        plan.set_grad_callback(owner.grad_ready_hook if direct else None)
         plan.backward(dy_last, dy_all if ctx.want_all else None, grads, dx=dx)
         ctx.lease.release()
+        if direct:
+            return (dx, None, None, None, None, *([None] * (4 * L)))
         flat = [g for group in grads for g in group]
         return (dx, None, None, None, None, *flat)
 
@@ -83,6 +96,10 @@ class HipLSTM(nn.Module):
         for name, p in ref.named_parameters():
             self.register_parameter(name, nn.Parameter(p.detach().clone()))
         self._plans = {}        # key -> list of plans; plan.busy marks a forward awaiting its backward
+        # set by a trainer that owns the gradient buffers (trainer.DistillTrainer): the backward writes each parameter's
+        # gradient straight into its .grad and calls grad_ready_hook(layer) as soon as a layer's gradients are enqueued
+        self.direct_grads = False
+        self.grad_ready_hook = None
 
     def _checkout(self, B, T, device, training):
         key = (B, T, str(device), bool(training), self.compute_dtype)

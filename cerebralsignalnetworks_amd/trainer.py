@@ -31,7 +31,16 @@ def dist_info():
 
 class FlatGrads:
     """All parameter gradients as views into one contiguous float32 buffer; with ``flatten_params`` the parameters
-    themselves too (same offsets), so that an optimiser can step the whole model in one pass."""
+    themselves too (same offsets), so that an optimiser can step the whole model in one pass.
+
+    Data-parallel reduction: ``all_reduce_mean()`` after the backward = one blocking all-reduce of the whole buffer
+    (31 MB at cfg2).  With ``segments`` (contiguous (start, end) element ranges in readiness order, set by
+    ``DistillTrainer``) the reduction is BUCKETED and OVERLAPPED the way DistributedDataParallel does it for the
+    reference (LstmDistillation.py:445): ``segment_ready(i)`` -- called from the LSTM backward's gradient-ready hook --
+    starts an asynchronous all-reduce of that range on the communication stream while the remaining layers'
+    weight-gradient GEMMs are still running; ``all_reduce_mean()`` then reduces what is left, waits for everything and
+    scales by 1 / world.  ``CSN_NO_AR_OVERLAP=1`` keeps the single blocking collective (A/B, and the form the overlapped
+    one is tested against)."""
 
     def __init__(self, params, flatten_params=False):
         self.params = [p for p in params if p.requires_grad]
@@ -39,6 +48,9 @@ class FlatGrads:
         self.flat = torch.zeros(total, dtype=torch.float32, device=self.params[0].device)
         self.flat_params = torch.empty_like(self.flat) if flatten_params else None
         self.timing = None      # a list -> all_reduce_mean() records an event pair per call
+        self.offsets = {}       # id(param) -> (first element, number of elements)
+        self.segments = None    # [(start, end)] in readiness order, or None = one blocking collective
+        self._pending, self._works = None, []
         off = 0
         for p in self.params:
             n = p.numel()
@@ -46,10 +58,35 @@ class FlatGrads:
             if flatten_params:
                 self.flat_params[off:off + n].copy_(p.data.reshape(-1))
                 p.data = self.flat_params[off:off + n].view_as(p)
+            self.offsets[id(p)] = (off, n)
             off += n
 
     def zero(self):
         self.flat.zero_()
+        self._pending = None if self.segments is None else [True] * len(self.segments)
+        self._works = []
+
+    def _reduce_runs(self, idx):
+        """async all-reduce of the segments ``idx`` (merged into contiguous runs: fewer, larger messages)"""
+        runs = []
+        for s, e in sorted(self.segments[i] for i in idx):
+            if runs and runs[-1][1] == s:
+                runs[-1][1] = e
+            else:
+                runs.append([s, e])
+        for s, e in runs:
+            if e > s:
+                self._works.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, async_op=True))
+
+    def segment_ready(self, i, also=()):
+        """Gradients of segment ``i`` (and of the segments ``also``, if still pending) are final on the current stream."""
+        _, world = dist_info()
+        if world == 1 or self._pending is None:
+            return
+        idx = [j for j in (i, *also) if self._pending[j]]
+        for j in idx:
+            self._pending[j] = False
+        self._reduce_runs(idx)
 
     def all_reduce_mean(self):
         rank, world = dist_info()
@@ -58,14 +95,23 @@ class FlatGrads:
             if self.timing is not None and self.flat.is_cuda:     # bench.py: event pair on the launching stream
                 ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                 ev[0].record()
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+            if self._pending is None:
+                dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+            else:
+                rest = [j for j, p in enumerate(self._pending) if p]
+                self._pending = [False] * len(self._pending)
+                self._reduce_runs(rest)
+                for w in self._works:
+                    w.wait()
+                self._works = []
             self.flat.div_(world)
             if ev is not None:
                 ev[1].record()
                 self.timing.append(ev)
 
     def all_reduce_ms(self):
-        """Mean milliseconds of the recorded gradient all-reduces (incl. the 1/world scaling); blocking."""
+        """Mean milliseconds between the end of the backward's launches and the reduced, scaled gradients on the launch
+        stream: the whole all-reduce in the blocking form, its EXPOSED part in the overlapped form; blocking."""
         if not self.timing:
             return None
         torch.cuda.synchronize()
@@ -96,9 +142,7 @@ class FlatRMSprop:
     @torch.no_grad()
     def step(self):
         from . import cabi
-        self._steps = getattr(self, "_steps", 0) + 1
-        if self._steps == 1 or self._steps % 256 == 0:
-            self.check_views()
+        self.check_views()      # (a dozen data_ptr() compares on the host: every step, so that a re-homed parameter is caught at once)
         cabi.rmsprop_step(self.flat.flat_params, self.flat.flat, self.square_avg, self.param_groups[0]["lr"], self.alpha, self.eps)
 
     def zero_grad(self, set_to_none=False):
@@ -203,6 +247,48 @@ class DistillTrainer:
         if world > 1:   # identical initial weights on every rank
             for p in model.parameters():
                 dist.broadcast(p.data, src=0)
+        self._wire_lstm_gradients(world)
+
+    def _wire_lstm_gradients(self, world):
+        """The model's HIP LSTM writes its gradients straight into the flat buffer (one forward per step uses it: no
+        temporaries, no accumulation pass), and -- data-parallel -- tells the buffer which layer's gradients are
+        enqueued, so that their all-reduce overlaps the weight-gradient GEMMs of the layers below (FlatGrads)."""
+        import os
+        from .lstm_model import HipLSTM
+        lstms = [m for m in self.model.modules() if isinstance(m, HipLSTM)]
+        self._hook_error = None
+        if len(lstms) != 1 or not self.grads.flat.is_cuda:
+            return
+        lstm = lstms[0]
+        lstm.direct_grads = True
+        L = lstm.num_layers
+        first = [self.grads.offsets[id(getattr(lstm, f"weight_ih_l{k}"))][0] for k in range(L)]
+        last = self.grads.offsets[id(getattr(lstm, f"bias_hh_l{L - 1}"))]
+        lstm_end = last[0] + last[1]
+        contiguous = all(first[k] < first[k + 1] for k in range(L - 1)) and first[0] == min(o for o, _ in self.grads.offsets.values())
+        if world == 1 or os.environ.get("CSN_NO_AR_OVERLAP") or not contiguous:
+            return
+        total = self.grads.flat.numel()
+        # segments: LSTM layer k = k, everything behind the LSTM's parameters (fc, class_pred) = L
+        self.grads.segments = [(first[k], first[k + 1] if k + 1 < L else lstm_end) for k in range(L)] + [(lstm_end, total)]
+        others = [p for p in self.grads.params if self.grads.offsets[id(p)][0] >= lstm_end]
+        self._others_left = len(others)
+        self._n_others = len(others)
+
+        def other_done(_p):
+            self._others_left -= 1
+        for p in others:
+            p.register_post_accumulate_grad_hook(other_done)
+
+        def layer_ready(layer):
+            try:
+                if layer == 0:
+                    return                      # the bottom layer's gradients come last: all_reduce_mean() takes them
+                # the head's gradients were accumulated before the LSTM's backward ran (autograd order); if not, they wait
+                self.grads.segment_ready(layer, also=(L,) if self._others_left == 0 else ())
+            except Exception as e:              # (a ctypes callback cannot raise: kept for train_step)
+                self._hook_error = e
+        lstm.grad_ready_hook = layer_ready
 
     def embed(self, eeg_bct):
         """raw EEG [B,C,T] (device, float32) -> model input [B,T,C]."""
@@ -236,16 +322,35 @@ class DistillTrainer:
         """One optimisation step on this rank's shard of the global batch; returns the (device) loss."""
         self.model.train()
         self.grads.zero()
+        if self.grads.segments is not None:
+            self._others_left = self._n_others
         x = self.embed(eeg_bct)
         out = self.model(x)
         loss = self.compute_loss(out, targets, labels, epoch)
         loss.backward()
+        if self._hook_error is not None:
+            err, self._hook_error = self._hook_error, None
+            raise err
         self.grads.all_reduce_mean()
         self.opt.step()
         return loss.detach()
 
     def check_device_status(self):
+        """The model's sticky device status (time-outs; non-finite gradients where the weight-stationary backward saw
+        them) AND, for every path -- the exact-f32 / per-diagonal kernels raise no status bit -- a finiteness test of the
+        parameters and of the last step's gradients: a NaN that any earlier step produced is still in the parameters."""
         check_device_status(self.model)
+        bufs = [self.grads.flat] + ([self.grads.flat_params] if self.grads.flat_params is not None else
+                                    [p.data for p in self.grads.params])
+        finite = torch.stack([torch.isfinite(b).all() for b in bufs]).all()
+        _, world = dist_info()
+        if world > 1:
+            t = (~finite).to(torch.int32).reshape(1)
+            t = t if dist.get_backend() == "nccl" else t.cpu()
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            finite = t.item() == 0
+        if not bool(finite):
+            raise FloatingPointError("non-finite (NaN / Inf) parameters or gradients: the run has diverged")
 
     @torch.no_grad()
     def embed_all(self, eeg_all, batch):

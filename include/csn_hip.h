@@ -36,7 +36,7 @@ enum csnStatus {
 enum csnDtype { CSN_F32 = 0, CSN_BF16 = 1 };
 
 /* ABI version of this header; bumped on any signature change. */
-#define CSN_ABI_VERSION 4
+#define CSN_ABI_VERSION 5
 int csn_abi_version(void);
 /* Thread-local message for the last non-zero status returned on this thread. */
 const char* csn_last_error(void);
@@ -107,6 +107,11 @@ int csn_lstm_plan_path(const csnLstmPlan* plan);
  * read in place by those GEMMs (experiments library under CSN_BWD_SINGLE_COPY); 0 = no backward has
  * run, or a path without hand-off slabs.  Diagnostic: lets a test see which form it compared. */
 int csn_lstm_plan_dgates_copies(const csnLstmPlan* plan);
+/* Name of the device function that advances the recurrence on this plan's path: which = 0 forward, 1 backward
+ * ("lstm_fwd_persist_kernel", "lstm_fwd_ns_kernel", "lstm_bwd_persist_kernel", "lstm_cell_fwd_il_kernel", ... -- the
+ * names a rocprofv3 kernel trace shows, without template arguments).  Diagnostic: bench.py labels its roofline object
+ * and looks up the committed counter passes with it.  Static storage; NULL for a null plan / other `which`. */
+const char* csn_lstm_plan_kernel_name(const csnLstmPlan* plan, int which);
 /* Same number without a plan (what csn_lstm_plan_workspace_bytes would return for a plan created now). */
 size_t csn_lstm_workspace_bytes(const csnLstmDesc* d, int training);
 
@@ -137,11 +142,27 @@ int csn_lstm_backward(csnLstmPlan* plan,
                       float* const* db_ih, float* const* db_hh,
                       float* dx, csnStream_t stream);
 
+/* Gradient-ready notification (data-parallel training: the reference gets the overlap of its gradient all-reduce with
+ * the backward from DistributedDataParallel's autograd hooks, LstmDistillation.py:445; this is the same hook at the C
+ * boundary).  csn_lstm_backward calls fn(user, layer) on the CALLING host thread, once per layer, top layer first,
+ * each time at a point where every kernel that writes dw_ih/dw_hh/db_ih/db_hh of `layer` has been enqueued on (or
+ * ordered before) `stream`: work the callback enqueues behind `stream` -- e.g. an all-reduce of that layer's gradients
+ * on a communication stream that waits on an event recorded there -- then runs beside the remaining layers' weight-
+ * gradient GEMMs.  The weight-stationary recurrence launches (one workgroup per CU, all co-resident) are all enqueued
+ * BEFORE the first call, so nothing the callback starts can share the device with them.  The callback must not call
+ * back into this plan.  fn = NULL removes it. */
+typedef void (*csnGradReadyFn)(void* user, int layer);
+int csn_lstm_plan_set_grad_callback(csnLstmPlan* plan, csnGradReadyFn fn, void* user);
+
 /* The workspace's status word: 0 = ok.  Bit CSN_STATUS_TIMEOUT: a bounded in-kernel wait of a weight-stationary
  * kernel gave up at some point since the word was last cleared (the results of that forward / backward and of every
  * later one are invalid).  Bit CSN_STATUS_NONFINITE: a NaN / Inf gradient reached the backward recurrence (the
  * operand was proven to be data, its product was not finite): the gradients are non-finite exactly as the reference's
- * autograd would leave them -- a diverged run, not a device fault.  It is STICKY: no forward or backward clears it.  csn_lstm_status_clear zeroes it (enqueued on
+ * autograd would leave them -- a diverged run, not a device fault.  Only the weight-stationary backward with the
+ * hand-off by data (csn_lstm_plan_path() == 3, not under CSN_BWD_FLAGS) inspects its operands and can raise this bit;
+ * on every other path (exact-f32, odd shapes, sequences too long for the slab ring) non-finite gradients simply
+ * propagate into dw / dx, and a caller that wants the check on every path tests its gradient buffer itself
+ * (trainer.check_device_status does).  It is STICKY: no forward or backward clears it.  csn_lstm_status_clear zeroes it (enqueued on
  * `stream`): call it once after allocating a workspace and after a reported error has been handled.
  * csn_lstm_status_read is a blocking device -> host read.  csn_lstm_status_raise is fault injection for tests of
  * the error path: it leaves the word exactly as a timed-out wait does (every later bounded wait then returns at

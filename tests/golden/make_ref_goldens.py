@@ -518,6 +518,84 @@ def ref_retrieval(n_gallery=2048, n_query=512, tag="cfg2", T=500, H=768, seed=10
                                          top5_dist=Dm, top1=np.array(top1), emb_sample=emb[::16].astype(np.float32)))
 
 
+# ------------------------------------------------------------------------------------------------
+# runtime helpers of utils/utils.py (meters, gradient clipping, parameter groups, accuracy)
+# ------------------------------------------------------------------------------------------------
+def ref_runtime():
+    """Executes the reference's SmoothedValue / MetricLogger / clip_gradients / cancel_gradients_last_layer /
+    get_params_groups / bool_flag / accuracy (utils/utils.py:132-149, 201-212, 224-284, 313-347, 506-513, 636-647)
+    on seeded inputs.  Strings are stored as fixed-width unicode arrays (no pickle)."""
+    import argparse
+    import datetime
+    import time
+    from collections import defaultdict, deque
+    ns = lift("utils/utils.py", ["SmoothedValue", "MetricLogger", "clip_gradients", "cancel_gradients_last_layer",
+                                 "get_params_groups", "bool_flag", "accuracy", "is_dist_avail_and_initialized",
+                                 "get_world_size", "get_rank", "is_main_process", "reduce_dict", "has_batchnorms"],
+              base_namespace(defaultdict=defaultdict, deque=deque, time=time, datetime=datetime, argparse=argparse))
+    out = {}
+    rng = np.random.default_rng(77)
+    series = rng.standard_normal(37).round(3)
+    for win in (20, 4, 5):
+        sv = ns["SmoothedValue"](window_size=win)
+        stats = []
+        for i, v in enumerate(series):
+            sv.update(float(v), n=1 + (i % 3))
+            stats.append([sv.median, sv.avg, sv.global_avg, sv.max, sv.value])
+        out[f"smoothed_w{win}"] = np.array(stats, dtype=np.float64)
+        out[f"smoothed_w{win}_str"] = np.array(str(sv))
+    out["series"] = series
+    ml = ns["MetricLogger"](delimiter="  ")
+    for i, v in enumerate(series[:11]):
+        ml.update(loss=torch.tensor(float(v)), lr=0.001 * (i + 1), step=i)
+    out["logger_str"] = np.array(str(ml))
+    out["logger_loss_global_avg"] = np.array(ml.loss.global_avg)
+    # clip_gradients / cancel_gradients_last_layer / get_params_groups on a small seeded module tree
+    torch.manual_seed(5)
+
+    class Head(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.mlp = nn.Linear(6, 5)
+            self.norm = nn.LayerNorm(5)
+            self.last_layer = nn.Linear(5, 3, bias=False)
+
+        def forward(self, x):
+            return self.last_layer(self.norm(self.mlp(x)))
+
+    net = Head()
+    x = torch.from_numpy(rng.standard_normal((4, 6)).astype(np.float32))
+    (net(x) ** 2).sum().backward()
+    names = [n for n, _ in net.named_parameters()]
+    out["clip_names"] = np.array(names)
+    for n, p in net.named_parameters():
+        out[f"clip_param__{n}"] = p.detach().numpy().copy()
+        out[f"clip_grad_before__{n}"] = p.grad.numpy().copy()
+    out["clip_x"] = x.numpy()
+    for clip in (0.3, 3.0):
+        saved = [p.grad.clone() for p in net.parameters()]
+        norms = ns["clip_gradients"](net, clip)
+        out[f"clip{clip}_norms"] = np.array(norms)
+        for n, p in net.named_parameters():
+            out[f"clip{clip}_grad_after__{n}"] = p.grad.numpy().copy()
+        for p, g in zip(net.parameters(), saved):
+            p.grad = g
+    groups = ns["get_params_groups"](net)
+    idx = {id(p): n for n, p in net.named_parameters()}
+    out["groups_regularized"] = np.array([idx[id(p)] for p in groups[0]["params"]])
+    out["groups_not_regularized"] = np.array([idx[id(p)] for p in groups[1]["params"]])
+    out["groups_wd1"] = np.array(groups[1]["weight_decay"])
+    ns["cancel_gradients_last_layer"](0, net, 1)
+    out["cancel_epoch0_none"] = np.array([n for n, p in net.named_parameters() if p.grad is None])
+    logits = torch.from_numpy(rng.standard_normal((16, 10)).astype(np.float32))
+    target = torch.from_numpy(rng.integers(0, 10, 16))
+    out["acc_logits"], out["acc_target"] = logits.numpy(), target.numpy()
+    out["acc_top1_5"] = np.array([float(a) for a in ns["accuracy"](logits, target, topk=(1, 5))])
+    out["bool_flag_true"] = np.array([ns["bool_flag"](s) for s in ("on", "True", "1")])
+    out["bool_flag_false"] = np.array([ns["bool_flag"](s) for s in ("off", "FALSE", "0")])
+    _save("ref_runtime.npz", out)
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "small"
     torch.manual_seed(0)
@@ -529,6 +607,8 @@ if __name__ == "__main__":
         ref_dino_step()
     if what in ("dino",):
         ref_dino_step()
+    if what in ("runtime", "small", "all"):
+        ref_runtime()
     if what in ("cfg2", "all"):
         ref_lstm_full("cfg2", 8, 500, 128, 768, 2, 384, seed_x=31)
     if what in ("cfg4", "all"):

@@ -716,8 +716,8 @@ def test_bench_two_ranks_rehearsal_on_one_device(cuda):
     import json
     import subprocess
     import sys
-    env = dict(os.environ, CSN_SINGLE_DEVICE="1", CSN_DIST_BACKEND="gloo", CSN_NO_PERSIST="1")
-    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+    env = dict(os.environ, CSN_SINGLE_DEVICE="1", CSN_DIST_BACKEND="gloo")     # (the launcher adds CSN_NO_PERSIST itself)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "CSN_NO_PERSIST"):
         env.pop(k, None)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
                           "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
@@ -726,6 +726,10 @@ def test_bench_two_ranks_rehearsal_on_one_device(cuda):
     dp = res["data_parallel"]
     assert res["n_gpus"] == 2 and dp["ranks_seen"] == 2 and dp["param_checksum_equal_on_all_ranks"] and dp["single_device_rehearsal"]
     assert res["parity"]["f32_within_1e-4"] and res["config"]["global_batch"] == 512
+    # a rehearsal line carries no throughput claim; the gradient all-reduce ran bucketed and overlapped (two messages)
+    assert res["value"] is None and res["rehearsal_value"] > 0
+    assert dp["allreduce_overlapped"] and len(dp["allreduce_segments_bytes"]) == 3 and dp["allreduce_exposed_ms_per_step"] > 0
+    assert sum(dp["allreduce_segments_bytes"]) == dp["allreduce_bytes"]
 
 
 def test_train_cli_two_ranks_rehearsal_on_one_device(cuda, tmp_path):
@@ -853,6 +857,104 @@ def test_cli_train_then_eval_cfg1(cuda, tmp_path):
     x = ds.eeg_all[b].cpu().numpy()
     feat = lstm.model_forward(eeg_filter.eeg_bandpass_znorm(x, filt.sos), p, 2)
     assert abs(loss.item() - losses.cosine_similarity_loss(feat, ds.features_all[b].cpu().numpy())) < 1e-4
+
+
+@pytest.mark.parametrize("B,T,C,H,L,dtype", [(8, 40, 16, 128, 2, torch.bfloat16), (5, 33, 12, 64, 3, torch.float32),
+                                             (256, 70, 128, 768, 2, torch.bfloat16), (64, 40, 128, 1024, 2, torch.bfloat16)])
+def test_direct_gradients_and_ready_hook(cuda, B, T, C, H, L, dtype):
+    """The trainer's LSTM writes its gradients straight into the flat buffer (no temporaries, no accumulation pass) and
+    announces every layer through csn_lstm_plan_set_grad_callback, top layer first, on every path (generic cells,
+    per-diagonal launches, weight-stationary): same bits as autograd's accumulation of the library's outputs."""
+    from cerebralsignalnetworks_amd.trainer import DistillTrainer
+    rng = np.random.default_rng(B + T)
+    x = dev_t(rng.standard_normal((B, C, T)).astype(np.float32), cuda)
+    tgt = dev_t(rng.standard_normal((B, 24)).astype(np.float32), cuda)
+    torch.manual_seed(3)
+    m_ref = Model(input_size=C, lstm_size=H, lstm_layers=L, output_size=24, include_top=False, compute_dtype=dtype).to(cuda)
+    m = Model(input_size=C, lstm_size=H, lstm_layers=L, output_size=24, include_top=False, compute_dtype=dtype).to(cuda)
+    m.load_state_dict(m_ref.state_dict())
+    CosineSimilarityLoss()(m_ref(x.transpose(1, 2).contiguous()), tgt).backward()
+    want = torch.cat([p.grad.reshape(-1) for p in m_ref.parameters()])
+    tr = DistillTrainer(m, None, loss="cosine", lr=1e-3, preprocess=False)
+    assert m.lstm.direct_grads and m.lstm.grad_ready_hook is None          # one rank: nothing to overlap
+    calls = []
+    m.lstm.grad_ready_hook = calls.append
+    tr.train_step(x, tgt)
+    assert calls == list(range(L - 1, -1, -1)), calls
+    assert torch.equal(tr.grads.flat, want)
+    tr.train_step(x, tgt)                                                   # a second step: the hook is re-armed per backward
+    assert calls == 2 * list(range(L - 1, -1, -1))
+    # without the trainer's contract (direct_grads off) the same module accumulates as any autograd function does
+    m.lstm.direct_grads = False
+    m.lstm.grad_ready_hook = None
+    tr.check_device_status()
+
+
+def test_transform_eeg_data_lstm_by_list_runs_the_hip_model(cuda):
+    """a12 (utils/PerilsEEGDataset.py:323-341): ``dataset.transformEEGDataLSTMByList(model, loader)`` with the HIP
+    ``Model`` over loaders of the dataset, as LstmDistillFromDinoV2Train.py:381-387 calls it: the rows against the
+    oracle's embeddings of the same items, the labels in both modes -- by dataset index, and (``compat_label_bug``) by
+    the position inside the batch, which is what the reference's ``getLabelbyIndex(idx)`` at :338 looks up."""
+    from torch.utils.data import DataLoader, Subset
+    from cerebralsignalnetworks_amd.dataset import EEGDataset
+    from cerebralsignalnetworks_amd.trainer import split_indices
+    torch.manual_seed(7)
+    N, C, T, H, D, bs = 90, 16, 48, 64, 24, 16
+    ds = EEGDataset(synthetic=N, synthetic_channels=C, synthetic_samples=T, time_low=0, time_high=T, seed=11, device=cuda,
+                    feature_dim=D)
+    m = Model(input_size=C, lstm_size=H, lstm_layers=2, output_size=D, include_top=False,
+              compute_dtype=torch.float32).to(cuda).eval()
+    p = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
+    tr, te = split_indices(N, (0.8, 0.2), seed=43)
+    for ix in (tr, te):
+        loader = DataLoader(Subset(ds, ix.tolist()), batch_size=bs, shuffle=False)
+        want = lstm.model_forward(ds.eeg_all[ix.to(cuda)].transpose(1, 2).double().cpu().numpy(), p, 2)    # items are eeg[T, C]
+        for compat in (False, True):
+            ds.compat_label_bug = compat
+            feats, labs = ds.transformEEGDataLSTMByList(model=m, data_loader=loader)
+            assert len(feats) == len(labs) == len(ix) and feats[0].shape == (D,)
+            np.testing.assert_allclose(np.stack(feats), want, atol=2e-5)
+            pos = [j % bs for j in range(len(ix))]                       # position of item j inside its batch
+            expect = [ds.getLabelbyIndex(pos[j] if compat else int(ix[j])) for j in range(len(ix))]
+            assert labs == expect
+    # include_top=True: the tuple output's features are taken (the product does not iterate over the tuple)
+    ds.compat_label_bug = False
+    m2 = Model(input_size=C, lstm_size=H, lstm_layers=1, output_size=D, include_top=True,
+               compute_dtype=torch.float32).to(cuda).eval()
+    feats, labs = ds.transformEEGDataLSTMByList(model=m2, data_loader=DataLoader(Subset(ds, te.tolist()), batch_size=bs))
+    assert len(feats) == len(te) and feats[0].shape == (D,)
+    # bf16 path through the same call: the default compute dtype of the CLIs
+    m3 = Model(input_size=C, lstm_size=128, lstm_layers=2, output_size=D, include_top=False).to(cuda).eval()
+    p3 = {k: v.detach().cpu().numpy() for k, v in m3.state_dict().items()}
+    feats, _ = ds.transformEEGDataLSTMByList(model=m3, data_loader=DataLoader(Subset(ds, te.tolist()), batch_size=bs))
+    want = lstm.model_forward(ds.eeg_all[te.to(cuda)].transpose(1, 2).double().cpu().numpy(), p3, 2)
+    np.testing.assert_allclose(np.stack(feats), want, atol=3e-2)
+    from cerebralsignalnetworks_amd.trainer import check_device_status
+    for mod in (m, m2, m3):
+        check_device_status(mod)
+
+
+def test_cli_compat_label_bug_changes_what_the_user_sees(cuda, tmp_path, capsys):
+    """--compat_label_bug routes the retrieval legs of both CLIs through transformEEGDataLSTMByList (the reference's
+    :381-387 / Eval :324-334): same embeddings, batch-local labels -> different Recall / Precision than the true labels."""
+    import LstmDistillFromDinoV2Train as train
+    import LstmDistillFromDinoV2Eval as evaluate_cli
+    base = ["--synthetic", "192", "--batch_size", "16", "--num_epochs", "2", "--validation_frequency", "1", "--log_dir",
+            str(tmp_path), "--hidden_size", "128", "--lstm_layers", "1", "--loss", "cosine", "--dtype", "f32", "--topK", "5"]
+    seen = {}
+    for tag, extra in (("true", []), ("compat", ["--compat_label_bug"])):
+        train.main(base + extra)
+        out = capsys.readouterr().out
+        line = [l for l in out.splitlines() if l.startswith("Overall Recall")][-1]
+        vline = [l for l in out.splitlines() if "val_loss:" in l][-1]
+        seen[tag] = (line, float(vline.split("val_loss:")[1].split()[0]))
+    assert seen["true"][0] != seen["compat"][0]                    # the flag is visible in the printed metrics
+    assert abs(seen["true"][1] - seen["compat"][1]) < 1e-6         # ... and touches nothing else (same seed, same training)
+    ckpt = os.path.join(str(tmp_path), "lstm_dinov2_best_loss.pth")
+    r0 = evaluate_cli.main(base + ["--custom_model_weights", ckpt])
+    r1 = evaluate_cli.main(base + ["--custom_model_weights", ckpt, "--compat_label_bug"])
+    np.testing.assert_array_equal(r0["I"], r1["I"])                # same embeddings, same neighbours
+    assert (r0["Recall_Total"], r0["Precision_Total"]) != (r1["Recall_Total"], r1["Precision_Total"])
 
 
 def test_featdist_and_kd_losses_train_on_gpu(cuda):

@@ -127,6 +127,48 @@ def test_flat_gradient_allreduce_two_process_gloo():
     np.testing.assert_array_equal(out[0], out[1])
 
 
+def _overlap_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    from cerebralsignalnetworks_amd.trainer import FlatGrads
+    res = {}
+    for mode in ("blocking", "overlapped", "overlapped_head_late"):
+        torch.manual_seed(0)
+        model = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Tanh(), torch.nn.Linear(5, 4), torch.nn.Tanh(), torch.nn.Linear(4, 3))
+        fg = FlatGrads(model.parameters())
+        n0 = sum(p.numel() for p in model[0].parameters())
+        n1 = n0 + sum(p.numel() for p in model[2].parameters())
+        if mode != "blocking":
+            fg.segments = [(0, n0), (n0, n1), (n1, fg.flat.numel())]     # "layer 0", "layer 1", "head"
+        x = torch.arange(24, dtype=torch.float32).reshape(4, 6) / 10 + rank
+        fg.zero()
+        model(x).pow(2).mean().backward()
+        if mode == "overlapped":
+            fg.segment_ready(1, also=(2,))          # top layer + head in one message while "layer 0" is still computing
+        elif mode == "overlapped_head_late":
+            fg.segment_ready(1)                     # the head's gradients were not final yet: they go with the rest
+        fg.all_reduce_mean()
+        res[mode] = fg.flat.clone().numpy()
+        assert fg._works == [] and (fg._pending is None or not any(fg._pending))
+    out[rank] = res
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bucketed_overlapped_allreduce_is_bit_identical_to_blocking_two_process_gloo():
+    """FlatGrads with readiness-ordered segments (the form the trainer's gradient-ready hook drives) against the single
+    blocking collective: same bits on both ranks, whichever way the head's segment is grouped."""
+    world, port = 2, 29651
+    out = mp.Manager().dict()
+    mp.spawn(_overlap_worker, args=(world, port, out), nprocs=world, join=True)
+    for r in range(world):
+        for mode in ("overlapped", "overlapped_head_late"):
+            np.testing.assert_array_equal(out[r][mode], out[r]["blocking"])
+    np.testing.assert_array_equal(out[0]["blocking"], out[1]["blocking"])
+    assert np.abs(out[0]["blocking"]).sum() > 0
+
+
 def test_classwise_channel_norm_matches_oracle_both_modes():
     """PerilsEEGDataset.transformEEGDataToChannelWiseNorm (:464-507): the intended normalisation and, behind a
     switch, the state the reference's stale-index / transposed-index code actually leaves."""
@@ -350,6 +392,13 @@ def test_bench_launcher_argv_env_and_rank_count_refusals():
     assert cmd[i + 1:] == argv                       # the ranks get the caller's flags verbatim (incl. --gpus 4)
     assert env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and "WORLD_SIZE" not in env and "RANK" not in env
     assert bench.parse(argv).gpus == 4
+    assert "CSN_NO_PERSIST" not in env or os.environ.get("CSN_NO_PERSIST")
+    # one-device rehearsal: the ranks' launches must be the per-diagonal ones (a weight-stationary launch owns every CU)
+    os.environ["CSN_SINGLE_DEVICE"] = "1"
+    try:
+        assert bench.launcher_command(2, ["--gpus", "2"], port=29877)[1]["CSN_NO_PERSIST"] == "1"
+    finally:
+        os.environ.pop("CSN_SINGLE_DEVICE")
     # no GPU in this container: asking for 2 must fail loudly, not print an n_gpus=1 line
     clean = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "CSN_SINGLE_DEVICE")}
     if torch.cuda.device_count() < 2:
