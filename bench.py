@@ -110,6 +110,9 @@ def parse(argv=None):
     ap.add_argument("--pool", type=int, default=4, help="resident synthetic batches per GPU")
     ap.add_argument("--config", default="cfg2", choices=["cfg2", "cfg4"],
                     help="cfg2 = BASELINE.json configs[1] (the headline); cfg4 = Spampinato shapes 128 x 440, hidden 1024")
+    ap.add_argument("--loss", default="cosine", choices=["cosine", "barlow"],
+                    help="cosine = the headline distillation step; barlow = BASELINE.json configs[4]: Barlow-Twins "
+                         "cross-correlation loss on the LSTM embeddings (HIP off-diagonal reduction) + LARS")
     ap.add_argument("--no-retrieval", action="store_true", help="skip the bf16-vs-CPU-reference retrieval acceptance")
     ap.add_argument("--no-f32-line", action="store_true", help="skip the short measurement of the exact-f32 path")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -246,7 +249,11 @@ def main():
     model = Model(input_size=C, lstm_size=H, lstm_layers=L, output_size=D, include_top=False,
                   compute_dtype=dtype).to(device)
     filt = EEGFilters(1000, order=3)
-    trainer = DistillTrainer(model, filt.sos, loss="cosine", lr=1e-3, optimizer="rmsprop")
+    if args.loss == "barlow":     # EEG-BarlowNetworks/train.py: LARS, lr from the warm-up / cosine schedule (its peak at batch 256 x world)
+        trainer = DistillTrainer(model, filt.sos, loss="barlow", lr=0.2, optimizer="lars")
+        args.no_parity = args.no_retrieval = args.no_f32_line = True      # (those companions describe the cosine step)
+    else:
+        trainer = DistillTrainer(model, filt.sos, loss="cosine", lr=1e-3, optimizer="rmsprop")
     x, tg, lab = synthetic_pool(B * args.pool, C, T, D, rank, device)
     parity = None
     ptag = {(128, 500, 768, 2, 384): "cfg2", (128, 440, 1024, 2, 384): "cfg4"}.get((C, T, H, L, D))
@@ -320,14 +327,17 @@ def main():
         seg_per_s = world * B * args.steps / elapsed
         flops_per_seg = 3.0 * 2.0 * T * sum(4 * H * ((C if l == 0 else H) + H) for l in range(L))
         res = {
-            "metric": f"EEG-segments/sec training ({C}ch x {T}, hidden={H})",
+            "metric": f"EEG-segments/sec training ({C}ch x {T}, hidden={H})" + (", Barlow-Twins loss" if args.loss == "barlow" else ""),
             "value": seg_per_s, "unit": "segments/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": ("cfg2" if (B, C, T, H, L, D) == (256, 128, 500, 768, 2, 384) else
+            "config": {"workload": (("cfg5 (1-GPU leg)" if args.loss == "barlow" else "cfg2") if (B, C, T, H, L, D) == (256, 128, 500, 768, 2, 384) else
                                     "cfg4" if (C, T, H, L, D) == (128, 440, 1024, 2, 384) else "custom") +
-                                   ": fused EEG band-pass+z-score -> LSTM fwd/bwd -> cosine distill "
-                                   "-> RMSprop, precomputed random DINOv2-dim targets",
+                                   (": fused EEG band-pass+z-score -> LSTM fwd/bwd -> Barlow-Twins cross-correlation loss "
+                                    "(BatchNorm, c = z1^T z2 / batch, HIP off-diagonal reduction) -> LARS, random image-embedding view"
+                                    if args.loss == "barlow" else
+                                    ": fused EEG band-pass+z-score -> LSTM fwd/bwd -> cosine distill "
+                                    "-> RMSprop, precomputed random DINOv2-dim targets"),
                        "per_gpu_batch": B, "global_batch": B * world, "channels": C, "samples": T, "hidden": H,
                        "layers": L, "embed_dim": D, "parallelism": f"dp{world}"},
             "final_loss": final_loss,

@@ -133,6 +133,22 @@ template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return
 __device__ __forceinline__ float sigmoid_f32(float x) { return 1.0f / (1.0f + expf(-x)); }
 __device__ __forceinline__ float tanh_f32(float x) { return tanhf(x); }
 
+// ---- generic / exact-f32 cell kernels (lstm_cell.hip) ------------------------------------
+// One launch advances up to 4 independent cell problems (blockIdx.z): the layers of a wavefront diagonal of the generic /
+// exact-f32 path (lstm.hip: forward_v1 / backward_v1) -- one launch boundary per timestep instead of one per layer-step.
+struct CellFwdOne {
+  const void* h_prev; const void* w_hh; const float* xproj; int64_t xproj_ld; const float* c_prev;
+  void* gates_out; float* c_out; void* h_out;
+};
+struct CellFwdBatch { CellFwdOne p[4]; };
+struct CellBwdOne {
+  const void* dg_next; const void* w_hh_t; const float* dy; int64_t dy_ld; const void* gates; const float* c;
+  const float* c_prev; float* dc_carry; void* dg_out;
+};
+struct CellBwdBatch { CellBwdOne p[4]; };
+int launch_cell_fwd_batch(const CellFwdBatch& b, int np, int B, int H, int dtype, hipStream_t st);
+int launch_cell_bwd_batch(const CellBwdBatch& b, int np, int B, int H, int dtype, hipStream_t st);
+
 // ---- internal launchers shared across translation units --------------------------------
 // out[r*ldo + c] = (T)in[strided]; generic strided cast used for the time-major input copy.
 int launch_cast_strided(const float* src, int64_t s0, int64_t s1, int64_t n0, int64_t n1, int64_t n2,

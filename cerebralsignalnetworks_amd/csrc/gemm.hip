@@ -802,6 +802,12 @@ gemm_nt_wide_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ Bt,
   const unsigned ntn = (unsigned)(N / BN);
   const unsigned ntiles = ntn * (unsigned)((M + 255) / 256);
   const int nk = (int)(K / 64);
+#if defined(CSN_NT_STAGGER)      // timing experiment (tools/abl_build.sh): every second first-wave workgroup of an XCD starts late, so that
+  if (blockIdx.x < 256u && ((blockIdx.x >> 3) & 1u)) {      // one half of the chip stores its tile while the other half streams operands
+    const unsigned long long t0_ = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0_ < (unsigned long long)(CSN_NT_STAGGER)) __builtin_amdgcn_s_sleep(8);
+  }
+#endif
   for (unsigned lid = xcd_remap(blockIdx.x, gridDim.x); lid < ntiles; lid += gridDim.x) {
   const int64_t m0 = (int64_t)(lid / ntn) * 256, n0 = (int64_t)(lid % ntn) * BN;
   __syncthreads();     // every wave has left the previous tile's last stage

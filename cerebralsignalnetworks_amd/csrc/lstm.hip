@@ -475,18 +475,23 @@ static int gemm_tn_full(const void* A, const void* B, float* C, int64_t M, int64
 // =============================================================================================
 // v1 path
 // =============================================================================================
+// Wavefront over the layers, as in the fast path: diagonal d runs layer l at step d - l * lag in ONE launch (blockIdx.z =
+// layer; round 3 ran layer after layer, one launch per layer-step: 2 T L launches per pass, each bound by its launch
+// boundary and its own fill, not by the float32 MFMA rate).  The input projection of layer l + 1 follows layer l chunk by
+// chunk (GEMM over `chunk` steps on the same stream), so lag = chunk.
 static int forward_v1(Plan& P, char* ws, const float* x, int64_t xsb, int64_t xst,
                       const float* const* w_ih, const float* const* w_hh, const float* const* b_ih,
                       const float* const* b_hh, int training, csnStream_t stream) {
   const csnLstmDesc* d = &P.d;
   const WsLayout& w = P.w;
   hipStream_t st = as_stream(stream);
-  const int B = d->B, T = d->T, H = d->H, dt = d->dtype;
+  const int B = d->B, T = d->T, H = d->H, dt = d->dtype, NL = d->L;
   const int64_t G = 4 * (int64_t)H, TB = (int64_t)T * B;
   const size_t es = dtype_size(dt);
+  const int Cz = P.opt.chunk, lag = Cz;
   int rc;
   if ((rc = launch_cast_strided(x, xsb, xst, B, T, d->I, ws + w.x_c, dt, st))) return rc;
-  for (int l = 0; l < d->L; ++l) {
+  for (int l = 0; l < NL; ++l) {
     const LayerWs& L = w.layer[l];
     const int64_t I = l == 0 ? d->I : H;
     if ((rc = launch_cast(w_ih[l], ws + L.wih, G * I, dt, st))) return rc;
@@ -496,21 +501,40 @@ static int forward_v1(Plan& P, char* ws, const float* x, int64_t xsb, int64_t xs
       if ((rc = launch_transpose_cast(w_ih[l], G, I, ws + L.wiht, dt, st))) return rc;
     }
     if ((rc = launch_add_vec(b_ih[l], b_hh[l], (float*)(ws + L.bias), G, st))) return rc;
-    const void* inp = l == 0 ? (const void*)(ws + w.x_c)
-                             : (const void*)(ws + w.layer[l - 1].h_all + (size_t)B * H * es);
-    if ((rc = gemm_nt(inp, ws + L.wih, (const float*)(ws + L.bias), ws + L.xproj, TB, G, I, dt, CSN_F32, 0,
-                          st, P.opt)))
-      return rc;
     CSN_HIP_CHECK(hipMemsetAsync(ws + L.h_all, 0, (size_t)B * H * es, st));
     CSN_HIP_CHECK(hipMemsetAsync(ws + L.c_all, 0, (size_t)B * H * 4, st));
-    for (int t = 0; t < T; ++t) {
-      rc = launch_cell_fwd(ws + L.h_all + (size_t)t * B * H * es, ws + L.whh,
-                           (const float*)(ws + L.xproj) + (size_t)t * B * G, G,
-                           (const float*)(ws + L.c_all) + (size_t)t * B * H,
-                           training ? ws + L.gates + (size_t)t * B * G * es : nullptr,
-                           (float*)(ws + L.c_all) + (size_t)(t + 1) * B * H,
-                           ws + L.h_all + (size_t)(t + 1) * B * H * es, B, H, dt, st);
-      if (rc) return rc;
+  }
+  // layer 0: projection of every step in one GEMM
+  if ((rc = gemm_nt(ws + w.x_c, ws + w.layer[0].wih, (const float*)(ws + w.layer[0].bias), ws + w.layer[0].xproj, TB, G,
+                    d->I, dt, CSN_F32, 0, st, P.opt)))
+    return rc;
+  const int D = T + lag * (NL - 1);
+  for (int dg = 0; dg < D; ++dg) {
+    CellFwdBatch b{};
+    int np = 0;
+    for (int l = 0; l < NL; ++l) {
+      const int t = dg - lag * l;
+      if (t < 0 || t >= T) continue;
+      const LayerWs& L = w.layer[l];
+      if (np == 4) {       // (more than 4 layers on one diagonal: a second launch, the problems are independent)
+        if ((rc = launch_cell_fwd_batch(b, np, B, H, dt, st))) return rc;
+        np = 0;
+      }
+      b.p[np++] = CellFwdOne{ws + L.h_all + (size_t)t * B * H * es, ws + L.whh, (const float*)(ws + L.xproj) + (size_t)t * B * G, G,
+                             (const float*)(ws + L.c_all) + (size_t)t * B * H,
+                             training ? ws + L.gates + (size_t)t * B * G * es : nullptr,
+                             (float*)(ws + L.c_all) + (size_t)(t + 1) * B * H, ws + L.h_all + (size_t)(t + 1) * B * H * es};
+    }
+    if (np > 0 && (rc = launch_cell_fwd_batch(b, np, B, H, dt, st))) return rc;
+    // a layer that just finished a chunk feeds the next layer's input projection
+    for (int l = 0; l + 1 < NL; ++l) {
+      const int t = dg - lag * l;
+      if (t < 0 || t >= T || ((t + 1) % Cz != 0 && t != T - 1)) continue;
+      const int t0 = (t / Cz) * Cz, nsteps = t - t0 + 1;
+      const LayerWs& Ln = w.layer[l + 1];
+      if ((rc = gemm_nt(ws + w.layer[l].h_all + (size_t)(t0 + 1) * B * H * es, ws + Ln.wih, (const float*)(ws + Ln.bias),
+                        (float*)(ws + Ln.xproj) + (size_t)t0 * B * G, (int64_t)nsteps * B, G, H, dt, CSN_F32, 0, st, P.opt)))
+        return rc;
     }
   }
   return CSN_OK;
@@ -522,25 +546,49 @@ static int backward_v1(Plan& P, char* ws, const float* dy_last, const float* dy_
   const csnLstmDesc* d = &P.d;
   const WsLayout& w = P.w;
   hipStream_t st = as_stream(stream);
-  const int B = d->B, T = d->T, H = d->H, dt = d->dtype;
+  const int B = d->B, T = d->T, H = d->H, dt = d->dtype, NL = d->L;
   const int64_t G = 4 * (int64_t)H, TB = (int64_t)T * B;
   const size_t es = dtype_size(dt);
+  const int Cz = P.opt.chunk, lag = Cz;
   int rc;
-  for (int l = d->L - 1; l >= 0; --l) {
+  for (int l = 0; l < NL; ++l) CSN_HIP_CHECK(hipMemsetAsync(ws + w.layer[l].dc_carry, 0, (size_t)B * H * 4, st));
+  // diagonal d: layer l at reverse step d - lag * (L - 1 - l); the gradient w.r.t. a layer's input (= dy of the layer
+  // below) follows chunk by chunk
+  const int D = T + lag * (NL - 1);
+  for (int dg = 0; dg < D; ++dg) {
+    CellBwdBatch b{};
+    int np = 0;
+    for (int l = NL - 1; l >= 0; --l) {
+      const int r = dg - lag * (NL - 1 - l);
+      if (r < 0 || r >= T) continue;
+      const int t = T - 1 - r;
+      const LayerWs& L = w.layer[l];
+      const bool top = (l == NL - 1);
+      if (np == 4) {
+        if ((rc = launch_cell_bwd_batch(b, np, B, H, dt, st))) return rc;
+        np = 0;
+      }
+      const float* dy_t = top ? (dy_tm ? dy_tm + (size_t)t * B * H : (t == T - 1 ? dy_last : nullptr))
+                              : (const float*)(ws + w.layer[l + 1].dx) + (size_t)t * B * H;
+      b.p[np++] = CellBwdOne{(t == T - 1) ? nullptr : (const void*)(ws + L.dgates + (size_t)(t + 1) * B * G * es), ws + L.whht, dy_t, H,
+                             ws + L.gates + (size_t)t * B * G * es, (const float*)(ws + L.c_all) + (size_t)(t + 1) * B * H,
+                             (const float*)(ws + L.c_all) + (size_t)t * B * H, (float*)(ws + L.dc_carry),
+                             ws + L.dgates + (size_t)t * B * G * es};
+    }
+    if (np > 0 && (rc = launch_cell_bwd_batch(b, np, B, H, dt, st))) return rc;
+    for (int l = NL - 1; l >= 1; --l) {
+      const int r = dg - lag * (NL - 1 - l);
+      if (r < 0 || r >= T || ((r + 1) % Cz != 0 && r != T - 1)) continue;
+      const int t_lo = T - 1 - r, t_hi = T - 1 - (r / Cz) * Cz;       // steps of this reverse chunk
+      const LayerWs& L = w.layer[l];
+      if ((rc = gemm_nt(ws + L.dgates + (size_t)t_lo * B * G * es, ws + L.wiht, nullptr, (float*)(ws + L.dx) + (size_t)t_lo * B * H,
+                        (int64_t)(t_hi - t_lo + 1) * B, H, G, dt, CSN_F32, 0, st, P.opt)))
+        return rc;
+    }
+  }
+  for (int l = NL - 1; l >= 0; --l) {
     const LayerWs& L = w.layer[l];
     const int64_t I = l == 0 ? d->I : H;
-    const bool top = (l == d->L - 1);
-    const float* dy_src = top ? dy_tm : (const float*)(ws + w.layer[l + 1].dx);
-    CSN_HIP_CHECK(hipMemsetAsync(ws + L.dc_carry, 0, (size_t)B * H * 4, st));
-    for (int t = T - 1; t >= 0; --t) {
-      const float* dy_t = dy_src ? dy_src + (size_t)t * B * H : ((top && t == T - 1) ? dy_last : nullptr);
-      const void* dg_next = (t == T - 1) ? nullptr : (const void*)(ws + L.dgates + (size_t)(t + 1) * B * G * es);
-      rc = launch_cell_bwd(dg_next, ws + L.whht, dy_t, H, ws + L.gates + (size_t)t * B * G * es,
-                           (const float*)(ws + L.c_all) + (size_t)(t + 1) * B * H,
-                           (const float*)(ws + L.c_all) + (size_t)t * B * H, (float*)(ws + L.dc_carry),
-                           ws + L.dgates + (size_t)t * B * G * es, B, H, dt, st);
-      if (rc) return rc;
-    }
     const void* inp = l == 0 ? (const void*)(ws + w.x_c)
                              : (const void*)(ws + w.layer[l - 1].h_all + (size_t)B * H * es);
     if ((rc = gemm_tn_full(ws + L.dgates, ws + L.h_all, dw_hh[l], G, H, TB, dt, ws + w.tn_scratch, st, P.opt))) return rc;
@@ -548,14 +596,12 @@ static int backward_v1(Plan& P, char* ws, const float* dy_last, const float* dy_
     if ((rc = launch_colsum(ws + L.dgates, TB, G, dt, db_ih[l], ws + w.colsum, st))) return rc;
     CSN_HIP_CHECK(hipMemcpyAsync(db_hh[l], db_ih[l], (size_t)G * 4, hipMemcpyDeviceToDevice, st));
     P.grads_ready(l);
-    if (l > 0 || dx) {
-      if ((rc = gemm_nt(ws + L.dgates, ws + L.wiht, nullptr, ws + L.dx, TB, I, G, dt, CSN_F32, 0, st, P.opt)))
-        return rc;
-      if (l == 0) {
-        tb_to_bt_kernel<<<grid_for(TB * I), 256, 0, st>>>((const float*)(ws + L.dx), dx, B, T, (int)I);
-        CSN_LAUNCH_CHECK();
-      }
-    }
+  }
+  if (dx) {
+    const LayerWs& L = w.layer[0];
+    if ((rc = gemm_nt(ws + L.dgates, ws + L.wiht, nullptr, ws + L.dx, TB, d->I, G, dt, CSN_F32, 0, st, P.opt))) return rc;
+    tb_to_bt_kernel<<<grid_for(TB * d->I), 256, 0, st>>>((const float*)(ws + L.dx), dx, B, T, d->I);
+    CSN_LAUNCH_CHECK();
   }
   return CSN_OK;
 }

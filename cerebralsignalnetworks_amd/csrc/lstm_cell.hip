@@ -50,14 +50,26 @@ template <> struct Frag<float> {
   }
 };
 
+#define CSN_CELL_FWD_BIND                                                                                    \
+  const CellFwdOne& q_ = batch.p[blockIdx.z];                                                                \
+  const T* __restrict__ h_prev = (const T*)q_.h_prev; const T* __restrict__ w_hh = (const T*)q_.w_hh;        \
+  const float* __restrict__ xproj = q_.xproj; const int64_t xproj_ld = q_.xproj_ld;                          \
+  const float* __restrict__ c_prev = q_.c_prev; T* __restrict__ gates_out = (T*)q_.gates_out;                \
+  float* __restrict__ c_out = q_.c_out; T* __restrict__ h_out = (T*)q_.h_out
+#define CSN_CELL_BWD_BIND                                                                                    \
+  const CellBwdOne& q_ = batch.p[blockIdx.z];                                                                \
+  const T* __restrict__ dg_next = (const T*)q_.dg_next; const T* __restrict__ w_hh_t = (const T*)q_.w_hh_t;  \
+  const float* __restrict__ dy = q_.dy; const int64_t dy_ld = q_.dy_ld; const T* __restrict__ gates = (const T*)q_.gates; \
+  const float* __restrict__ c = q_.c; const float* __restrict__ c_prev = q_.c_prev;                          \
+  float* __restrict__ dc_carry = q_.dc_carry; T* __restrict__ dg_out = (T*)q_.dg_out
+
 // ------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------
 template <typename T>
 __global__ void __launch_bounds__(256)
-lstm_cell_fwd_kernel(const T* __restrict__ h_prev, const T* __restrict__ w_hh, const float* __restrict__ xproj,
-                     int64_t xproj_ld, const float* __restrict__ c_prev, T* __restrict__ gates_out,
-                     float* __restrict__ c_out, T* __restrict__ h_out, int B, int H) {
+lstm_cell_fwd_kernel(CellFwdBatch batch, int B, int H) {
+  CSN_CELL_FWD_BIND;
   typedef Frag<T> F;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int u0 = blockIdx.x * 16;
@@ -123,10 +135,8 @@ lstm_cell_fwd_kernel(const T* __restrict__ h_prev, const T* __restrict__ w_hh, c
 // ------------------------------------------------------------------------------------------
 template <typename T>
 __global__ void __launch_bounds__(256)
-lstm_cell_bwd_kernel(const T* __restrict__ dg_next, const T* __restrict__ w_hh_t, const float* __restrict__ dy,
-                     int64_t dy_ld, const T* __restrict__ gates, const float* __restrict__ c,
-                     const float* __restrict__ c_prev, float* __restrict__ dc_carry, T* __restrict__ dg_out, int B,
-                     int H) {
+lstm_cell_bwd_kernel(CellBwdBatch batch, int B, int H) {
+  CSN_CELL_BWD_BIND;
   typedef Frag<T> F;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int u0 = blockIdx.x * 16;
@@ -231,9 +241,8 @@ __device__ __forceinline__ void cell_fwd_epilogue(f32x4 (&acc)[4], int mrow, int
 
 template <typename T>
 __global__ void __launch_bounds__(256)
-lstm_cell_fwd_ks_kernel(const T* __restrict__ h_prev, const T* __restrict__ w_hh, const float* __restrict__ xproj,
-                        int64_t xproj_ld, const float* __restrict__ c_prev, T* __restrict__ gates_out,
-                        float* __restrict__ c_out, T* __restrict__ h_out, int B, int H) {
+lstm_cell_fwd_ks_kernel(CellFwdBatch batch, int B, int H) {
+  CSN_CELL_FWD_BIND;
   typedef Frag<T> F;
   // partial tiles on their way to the wave that finishes them: [dst row group][src wave, without dst][gate][lane]
   __shared__ f32x4 part[4][3][4][64];
@@ -308,10 +317,8 @@ lstm_cell_fwd_ks_kernel(const T* __restrict__ h_prev, const T* __restrict__ w_hh
 
 template <typename T>
 __global__ void __launch_bounds__(512)
-lstm_cell_bwd_ks_kernel(const T* __restrict__ dg_next, const T* __restrict__ w_hh_t, const float* __restrict__ dy,
-                        int64_t dy_ld, const T* __restrict__ gates, const float* __restrict__ c,
-                        const float* __restrict__ c_prev, float* __restrict__ dc_carry, T* __restrict__ dg_out, int B,
-                        int H) {
+lstm_cell_bwd_ks_kernel(CellBwdBatch batch, int B, int H) {
+  CSN_CELL_BWD_BIND;
   typedef Frag<T> F;
   // 32 rows x 32 units per workgroup, K = 4H in 8 slices (one per wave): 192 workgroups at B 256 / H 768 -- 64 x 32 tiles
   // would read less (113 instead of 151 MB per launch) but fill only 96 CUs
@@ -436,53 +443,47 @@ lstm_cell_bwd_ks_kernel(const T* __restrict__ dg_next, const T* __restrict__ w_h
 // the K-split kernels need K slices (forward: H / 4; backward: 4H / 8 = H / 2) that are whole numbers of 128-byte lines
 static bool cell_ks_ok(int H, int dtype) { return H % (8 * (dtype == CSN_BF16 ? 32 : 16)) == 0; }     // whole lines per K slice
 
-int launch_cell_fwd(const void* h_prev, const void* w_hh, const float* xproj, int64_t xproj_ld, const float* c_prev,
-                    void* gates_out, float* c_out, void* h_out, int B, int H, int dtype, hipStream_t st) {
+int launch_cell_fwd_batch(const CellFwdBatch& b, int np, int B, int H, int dtype, hipStream_t st) {
+  CSN_REQUIRE(np >= 1 && np <= 4, "launch_cell_fwd_batch: %d problems", np);
   if (cell_ks_ok(H, dtype)) {
-    dim3 gridk((unsigned)(H / 16), (unsigned)((B + 63) / 64));
-    if (dtype == CSN_BF16)
-      lstm_cell_fwd_ks_kernel<bf16_t><<<gridk, 256, 0, st>>>((const bf16_t*)h_prev, (const bf16_t*)w_hh, xproj, xproj_ld,
-                                                             c_prev, (bf16_t*)gates_out, c_out, (bf16_t*)h_out, B, H);
-    else
-      lstm_cell_fwd_ks_kernel<float><<<gridk, 256, 0, st>>>((const float*)h_prev, (const float*)w_hh, xproj, xproj_ld,
-                                                            c_prev, (float*)gates_out, c_out, (float*)h_out, B, H);
-    CSN_LAUNCH_CHECK();
-    return CSN_OK;
+    dim3 gridk((unsigned)(H / 16), (unsigned)((B + 63) / 64), (unsigned)np);
+    if (dtype == CSN_BF16) lstm_cell_fwd_ks_kernel<bf16_t><<<gridk, 256, 0, st>>>(b, B, H);
+    else lstm_cell_fwd_ks_kernel<float><<<gridk, 256, 0, st>>>(b, B, H);
+  } else {
+    dim3 grid((unsigned)(H / 16), (unsigned)((B + 63) / 64), (unsigned)np);
+    if (dtype == CSN_BF16) lstm_cell_fwd_kernel<bf16_t><<<grid, 256, 0, st>>>(b, B, H);
+    else lstm_cell_fwd_kernel<float><<<grid, 256, 0, st>>>(b, B, H);
   }
-  dim3 grid((unsigned)(H / 16), (unsigned)((B + 63) / 64));
-  if (dtype == CSN_BF16)
-    lstm_cell_fwd_kernel<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)h_prev, (const bf16_t*)w_hh, xproj, xproj_ld,
-                                                       c_prev, (bf16_t*)gates_out, c_out, (bf16_t*)h_out, B, H);
-  else
-    lstm_cell_fwd_kernel<float><<<grid, 256, 0, st>>>((const float*)h_prev, (const float*)w_hh, xproj, xproj_ld, c_prev,
-                                                      (float*)gates_out, c_out, (float*)h_out, B, H);
   CSN_LAUNCH_CHECK();
   return CSN_OK;
 }
+int launch_cell_fwd(const void* h_prev, const void* w_hh, const float* xproj, int64_t xproj_ld, const float* c_prev,
+                    void* gates_out, float* c_out, void* h_out, int B, int H, int dtype, hipStream_t st) {
+  CellFwdBatch b{};
+  b.p[0] = CellFwdOne{h_prev, w_hh, xproj, xproj_ld, c_prev, gates_out, c_out, h_out};
+  return launch_cell_fwd_batch(b, 1, B, H, dtype, st);
+}
 
+int launch_cell_bwd_batch(const CellBwdBatch& b, int np, int B, int H, int dtype, hipStream_t st) {
+  CSN_REQUIRE(np >= 1 && np <= 4, "launch_cell_bwd_batch: %d problems", np);
+  if (cell_ks_ok(H, dtype)) {
+    dim3 gridk((unsigned)(H / 32), (unsigned)((B + 31) / 32), (unsigned)np);
+    if (dtype == CSN_BF16) lstm_cell_bwd_ks_kernel<bf16_t><<<gridk, 512, 0, st>>>(b, B, H);
+    else lstm_cell_bwd_ks_kernel<float><<<gridk, 512, 0, st>>>(b, B, H);
+  } else {
+    dim3 grid((unsigned)(H / 16), (unsigned)((B + 63) / 64), (unsigned)np);
+    if (dtype == CSN_BF16) lstm_cell_bwd_kernel<bf16_t><<<grid, 256, 0, st>>>(b, B, H);
+    else lstm_cell_bwd_kernel<float><<<grid, 256, 0, st>>>(b, B, H);
+  }
+  CSN_LAUNCH_CHECK();
+  return CSN_OK;
+}
 int launch_cell_bwd(const void* dg_next, const void* w_hh_t, const float* dy, int64_t dy_ld, const void* gates,
                     const float* c, const float* c_prev, float* dc_carry, void* dg_out, int B, int H, int dtype,
                     hipStream_t st) {
-  if (cell_ks_ok(H, dtype)) {
-    dim3 gridk((unsigned)(H / 32), (unsigned)((B + 31) / 32));
-    if (dtype == CSN_BF16)
-      lstm_cell_bwd_ks_kernel<bf16_t><<<gridk, 512, 0, st>>>((const bf16_t*)dg_next, (const bf16_t*)w_hh_t, dy, dy_ld,
-                                                             (const bf16_t*)gates, c, c_prev, dc_carry, (bf16_t*)dg_out, B, H);
-    else
-      lstm_cell_bwd_ks_kernel<float><<<gridk, 512, 0, st>>>((const float*)dg_next, (const float*)w_hh_t, dy, dy_ld,
-                                                            (const float*)gates, c, c_prev, dc_carry, (float*)dg_out, B, H);
-    CSN_LAUNCH_CHECK();
-    return CSN_OK;
-  }
-  dim3 grid((unsigned)(H / 16), (unsigned)((B + 63) / 64));
-  if (dtype == CSN_BF16)
-    lstm_cell_bwd_kernel<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)dg_next, (const bf16_t*)w_hh_t, dy, dy_ld,
-                                                       (const bf16_t*)gates, c, c_prev, dc_carry, (bf16_t*)dg_out, B, H);
-  else
-    lstm_cell_bwd_kernel<float><<<grid, 256, 0, st>>>((const float*)dg_next, (const float*)w_hh_t, dy, dy_ld,
-                                                      (const float*)gates, c, c_prev, dc_carry, (float*)dg_out, B, H);
-  CSN_LAUNCH_CHECK();
-  return CSN_OK;
+  CellBwdBatch b{};
+  b.p[0] = CellBwdOne{dg_next, w_hh_t, dy, dy_ld, gates, c, c_prev, dc_carry, dg_out};
+  return launch_cell_bwd_batch(b, 1, B, H, dtype, st);
 }
 
 }  // namespace csn

@@ -338,8 +338,9 @@ class DistillTrainer:
     def check_device_status(self):
         """The model's sticky device status (time-outs; non-finite gradients where the weight-stationary backward saw
         them) AND, for every path -- the exact-f32 / per-diagonal kernels raise no status bit -- a finiteness test of the
-        parameters and of the last step's gradients: a NaN that any earlier step produced is still in the parameters."""
-        check_device_status(self.model)
+        parameters and of the last step's gradients: a NaN that any earlier step produced is still in the parameters.
+        Like the status word it reports ONCE: a state already reported (by this test or by the status word: a timed-out
+        run leaves garbage) is not raised again at the next check."""
         bufs = [self.grads.flat] + ([self.grads.flat_params] if self.grads.flat_params is not None else
                                     [p.data for p in self.grads.params])
         finite = torch.stack([torch.isfinite(b).all() for b in bufs]).all()
@@ -349,7 +350,11 @@ class DistillTrainer:
             t = t if dist.get_backend() == "nccl" else t.cpu()
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             finite = t.item() == 0
-        if not bool(finite):
+        finite = bool(finite)
+        reported_before = getattr(self, "_nonfinite_reported", False)
+        self._nonfinite_reported = not finite
+        check_device_status(self.model)          # (raises for a time-out / a non-finite gradient seen on the device)
+        if not finite and not reported_before:
             raise FloatingPointError("non-finite (NaN / Inf) parameters or gradients: the run has diverged")
 
     @torch.no_grad()

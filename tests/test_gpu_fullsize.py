@@ -15,7 +15,7 @@ import torch
 
 from cerebralsignalnetworks_amd import cabi, Model, CosineSimilarityLoss, EEGFilters
 from cerebralsignalnetworks_amd.dataset import clustered_eeg
-from oracle import eeg_filter, lstm
+from oracle import eeg_filter, losses, lstm
 
 pytestmark = pytest.mark.gpu
 
@@ -408,6 +408,41 @@ def test_dino_self_distillation_step_matches_reference_fixture(cuda, golden):
             np.testing.assert_allclose(par.grad.cpu().numpy(), want, atol=1e-4 * max(1e-3, np.abs(want).max()), err_msg=name)
             checked += 1
     assert checked >= 14
+
+
+def test_barlow_step_at_cfg5_width(cuda):
+    """BASELINE.json configs[4] on one GPU at its real width: the Barlow-Twins loss (EEG-BarlowNetworks/net.py:33-42) on
+    the cfg2 encoder's embeddings -- B 256, D 384, 128 x 500 segments through the band-pass, H 768 x 2 layers, bf16 --
+    with the HIP off-diagonal reduction on the 384 x 384 cross-correlation matrix and one LARS step (optim.py:17-44).
+    The loss is held to the oracle's on the same embeddings, the reduction to the oracle's on the same c, the step to the
+    oracle's LARS on the device's gradients (the optimizer itself is pinned to the executed reference in the CPU suite)."""
+    from cerebralsignalnetworks_amd.trainer import DistillTrainer
+    B, C, T, H, L, D = 256, 128, 500, 768, 2, 384
+    x = torch.from_numpy(eeg_filter.synthetic_eeg(B, C, T, seed=51)).to(cuda)
+    tgt_np = np.random.default_rng(52).standard_normal((B, D)).astype(np.float32)
+    tgt = torch.from_numpy(tgt_np).to(cuda)
+    torch.manual_seed(43)
+    m = Model(input_size=C, lstm_size=H, lstm_layers=L, output_size=D, include_top=False).to(cuda)
+    lr = 0.2
+    tr = DistillTrainer(m, EEGFilters(1000, order=3).sos, loss="barlow", optimizer="lars", lr=lr)
+    before = {n: p.detach().clone() for n, p in m.named_parameters()}
+    with torch.no_grad():
+        feat = m(tr.embed(x)).float()
+    loss = tr.train_step(x, tgt)
+    tr.check_device_status()
+    want, c = losses.barlow_loss(feat.double().cpu().numpy(), tgt_np, B)
+    assert abs(loss.item() - want) < 1e-4 * want, (loss.item(), want)
+    # K7 on the full-width matrix
+    got = cabi.barlow_offdiag_sqsum(torch.from_numpy(c.astype(np.float32)).to(cuda)).cpu().numpy()
+    c32 = c.astype(np.float32).astype(np.float64)
+    np.testing.assert_allclose(got, [((np.diagonal(c32) - 1.0) ** 2).sum(), losses.off_diagonal_sqsum(c32)], rtol=2e-6)
+    # one LARS step from zero momentum on the gradients the device produced (they are still in the flat buffer)
+    for n, p in m.named_parameters():
+        g = p.grad.double().cpu().numpy()
+        new_p, _ = losses.lars_step(before[n].double().cpu().numpy(), g, np.zeros_like(g), lr, weight_decay=1e-6,
+                                    weight_decay_filter=True, lars_adaptation_filter=True)
+        np.testing.assert_allclose(p.detach().cpu().numpy(), new_p, rtol=0, atol=2e-6 * max(1.0, float(np.abs(new_p).max())), err_msg=n)
+        assert np.isfinite(g).all() and np.abs(g).max() > 0, n
 
 
 def test_fused_flat_rmsprop_matches_torch(cuda):

@@ -27,12 +27,12 @@ for g in "${groups[@]}"; do
   fi
   i=$((i+1))
 done
-python3 - "$out" <<'PY'
+python3 - "$out" "$*" <<'PY'
 import csv, glob, json, sys, collections
-names = ["lstm_bwd_persist_kernel", "lstm_fwd_persist_kernel", "gemm_nt_wide_kernel", "gemm_nt_256_kernel", "gemm_nt_dma_kernel", "gemm_tn_256_kernel",
+names = ["lstm_bwd_persist_kernel", "lstm_fwd_persist_kernel", "lstm_fwd_ns_kernel", "gemm_nt_wide_kernel", "gemm_nt_256_kernel", "gemm_nt_dma_kernel", "gemm_tn_256_kernel",
          "gemm_tn_bf16_kernel", "gemm_tn_n128_kernel", "eeg_filter_scan_kernel", "lstm_cell_fwd_il_kernel", "lstm_cell_bwd_il_kernel",
          "rmsprop_flat_kernel"]
-res = {"command": "rocprofv3 --pmc <group> --kernel-trace -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-retrieval --no-f32-line --no-parity (one pass per group)",
+res = {"bench_args": sys.argv[2], "command": "rocprofv3 --pmc <group> --kernel-trace -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-retrieval --no-f32-line --no-parity (one pass per group)",
        "note": "per-launch averages; SQ_* cycle counters other than SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES count quad-cycles summed over waves; "
                "GRBM_GUI_ACTIVE is summed over the 8 XCDs", "kernels": {}}
 for d in open("gpurun_out/pmcc_index.txt").read().split():

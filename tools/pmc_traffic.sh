@@ -1,19 +1,20 @@
 #!/bin/bash
-# usage (GPU box): tools/pmc_traffic.sh <out.json>
+# usage (GPU box): tools/pmc_traffic.sh <out.json> [extra bench.py args, e.g. --config cfg4]
 # HBM traffic per kernel launch of the bench workload: FETCH_SIZE and WRITE_SIZE in SEPARATE rocprofv3 --pmc passes
 # (never together with other trace domains), corrected as MI355X_MICROARCH.md "HBM" prescribes for gfx950.
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 out=${1:-gpurun_out/pmc_traffic.json}
+shift
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf gpurun_out/pmcb_$c
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmcb_$c -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-retrieval --no-f32-line --no-parity > gpurun_out/pmcb_$c.log 2>&1 || { echo "pass $c failed"; tail -5 gpurun_out/pmcb_$c.log; exit 1; }
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmcb_$c -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-retrieval --no-f32-line --no-parity "$@" > gpurun_out/pmcb_$c.log 2>&1 || { echo "pass $c failed"; tail -5 gpurun_out/pmcb_$c.log; exit 1; }
 done
-python3 - "$out" <<'PY'
+python3 - "$out" "$*" <<'PY'
 import csv, glob, json, sys, collections
-res = {"command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE (separate passes) --kernel-trace -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-retrieval --no-f32-line --no-parity",
+res = {"bench_args": sys.argv[2], "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE (separate passes) --kernel-trace -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-retrieval --no-f32-line --no-parity",
        "units": "counter values are KiB per dispatch; corrected = (2*FETCH_SIZE + WRITE_SIZE)*1024 bytes (gfx950: FETCH_SIZE counts 128-B requests as 64 B)",
        "kernels": {}}
-names = ["lstm_bwd_persist_kernel", "lstm_fwd_persist_kernel", "gemm_nt_wide_kernel", "gemm_nt_256_kernel", "gemm_nt_dma_kernel", "gemm_nt_bf16_kernel",
+names = ["lstm_bwd_persist_kernel", "lstm_fwd_persist_kernel", "lstm_fwd_ns_kernel", "gemm_nt_wide_kernel", "gemm_nt_256_kernel", "gemm_nt_dma_kernel", "gemm_nt_bf16_kernel",
          "gemm_tn_256_kernel", "gemm_tn_bf16_kernel", "eeg_filter_scan_kernel", "colsum_partial_kernel", "lstm_cell_bwd_il_kernel"]
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     f = glob.glob(f"gpurun_out/pmcb_{c}/**/*counter_collection.csv", recursive=True)[0]
