@@ -39,8 +39,15 @@ class FlatGrads:
     reference (LstmDistillation.py:445): ``segment_ready(i)`` -- called from the LSTM backward's gradient-ready hook --
     starts an asynchronous all-reduce of that range on the communication stream while the remaining layers'
     weight-gradient GEMMs are still running; ``all_reduce_mean()`` then reduces what is left, waits for everything and
-    scales by 1 / world.  ``CSN_NO_AR_OVERLAP=1`` keeps the single blocking collective (A/B, and the form the overlapped
-    one is tested against)."""
+    scales by 1 / world.
+
+    Which form is the DEFAULT is a measurement this repository could not make (no multi-GPU node was available to a
+    builder round): ``CSN_AR_OVERLAP=1`` selects the overlapped form, the default is the single blocking collective.
+    Reason for the caution: the kernels the collective would run beside are the weight-gradient GEMMs, grids of exactly
+    one 512-thread / 160 KB-LDS workgroup per CU -- an RCCL kernel that holds k CUs when such a grid is dispatched pushes
+    k of its tiles into a second wave (a 0.5 ms kernel becomes a 1 ms kernel), which would cost more than the 0.2 ms of
+    exposed all-reduce the overlap can hide.  Both forms give the same bits (2-rank test) and the bench line says which
+    one ran (``data_parallel.allreduce_overlapped``, ``allreduce_exposed_ms_per_step``)."""
 
     def __init__(self, params, flatten_params=False):
         self.params = [p for p in params if p.requires_grad]
@@ -266,7 +273,7 @@ class DistillTrainer:
         last = self.grads.offsets[id(getattr(lstm, f"bias_hh_l{L - 1}"))]
         lstm_end = last[0] + last[1]
         contiguous = all(first[k] < first[k + 1] for k in range(L - 1)) and first[0] == min(o for o, _ in self.grads.offsets.values())
-        if world == 1 or os.environ.get("CSN_NO_AR_OVERLAP") or not contiguous:
+        if world == 1 or not os.environ.get("CSN_AR_OVERLAP") or not contiguous:
             return
         total = self.grads.flat.numel()
         # segments: LSTM layer k = k, everything behind the LSTM's parameters (fc, class_pred) = L

@@ -716,7 +716,7 @@ def test_bench_two_ranks_rehearsal_on_one_device(cuda):
     import json
     import subprocess
     import sys
-    env = dict(os.environ, CSN_SINGLE_DEVICE="1", CSN_DIST_BACKEND="gloo")     # (the launcher adds CSN_NO_PERSIST itself)
+    env = dict(os.environ, CSN_SINGLE_DEVICE="1", CSN_DIST_BACKEND="gloo", CSN_AR_OVERLAP="1")     # (the launcher adds CSN_NO_PERSIST itself)
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "CSN_NO_PERSIST"):
         env.pop(k, None)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
