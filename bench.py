@@ -311,7 +311,8 @@ def main():
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
         dp = {"ranks_seen": int(ones.item()), "param_checksum": int(csum.item()),
               "param_checksum_equal_on_all_ranks": bool(lo.item() == hi.item()),
-              "allreduce_exposed_ms_per_step": trainer.grads.all_reduce_ms(),
+              "allreduce_exposed_ms_per_step": trainer.grads.all_reduce_ms(),      # end of the backward's launches -> reduced, scaled gradients
+              "allreduce_ms_per_step": None if trainer.grads.segments is not None else trainer.grads.all_reduce_ms(),   # (blocking form: the whole collective)
               "allreduce_overlapped": trainer.grads.segments is not None,
               "allreduce_segments_bytes": [4 * (e - s_) for s_, e in (trainer.grads.segments or [(0, trainer.grads.flat.numel())])],
               "allreduce_bytes": trainer.grads.flat.numel() * 4,

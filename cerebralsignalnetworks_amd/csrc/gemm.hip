@@ -830,15 +830,21 @@ gemm_nt_wide_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ Bt,
     const int ch = (lane & 7) ^ ((row >> 1) & 7);
     b_src[i] = Bt + (n0 + row) * K + ch * 8;
   }
+#if defined(CSN_NT_ROT)     // timing experiment: the column tiles that share an A panel (and the row tiles that share a B panel) start
+  const int nrot_ = (int)(lid % (unsigned)nk);      // their k walk at different steps, so that they are not all on the same lines at once
+#else
+  const int nrot_ = 0;
+#endif
+  auto kpos = [&](int kt) { const int k = kt + nrot_; return (int64_t)(k >= nk ? k - nk : k) * 64; };
   auto issue_a = [&](int kt) {
     char* a_s = smem + (kt % 3) * 32768;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) glds16(a_src[i] + (int64_t)kt * 64, a_s + (8 * i + wave) * 1024);
+    for (int i = 0; i < 4; ++i) glds16(a_src[i] + kpos(kt), a_s + (8 * i + wave) * 1024);
   };
   auto issue_b = [&](int kt) {
     char* b_s = smem + kBBase + (kt % 2) * kBStage;
 #pragma unroll
-    for (int i = 0; i < NBI; ++i) glds16(b_src[i] + (int64_t)kt * 64, b_s + (8 * i + wave) * 1024);
+    for (int i = 0; i < NBI; ++i) glds16(b_src[i] + kpos(kt), b_s + (8 * i + wave) * 1024);
   };
 
   const unsigned sw = (unsigned)((lane & 15) >> 1);
@@ -979,13 +985,22 @@ gemm_tn_256_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ Bm, 
     a_src[i] = a_blocked ? A + blk_offset(kbeg + kr, am, M) : A + (kbeg + kr) * M + am;
     b_src[i] = Bm + (kbeg + kr) * N + bn;
   }
+#if defined(CSN_TN_ROT)     // timing experiment (tools/abl_build.sh): every tile of a K slab starts its walk a few stages further on
+  const int rot_ = nh > CSN_TN_ROT ? (int)(rem % (unsigned)(CSN_TN_ROT)) : 0;
+#endif
   auto issue = [&](int h) {
     char* a_s = smem + (h % NSTAGE) * 32768;
     char* b_s = a_s + 16384;
+#if defined(CSN_TN_ROT)
+    const int hs_ = h + rot_;
+    const int64_t hr = hs_ >= nh ? hs_ - nh : hs_;
+#else
+    const int64_t hr = h;
+#endif
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      glds16(a_src[i] + (int64_t)h * 32 * M, a_s + (8 * i + wave) * 1024);
-      glds16(b_src[i] + (int64_t)h * 32 * N, b_s + (8 * i + wave) * 1024);
+      glds16(a_src[i] + hr * 32 * M, a_s + (8 * i + wave) * 1024);
+      glds16(b_src[i] + hr * 32 * N, b_s + (8 * i + wave) * 1024);
     }
   };
 
