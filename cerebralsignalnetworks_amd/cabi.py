@@ -269,6 +269,9 @@ class LstmPlan:
     def set_grad_callback(self, fn):
         """fn(layer) is called on this thread from inside backward() once layer's gradient kernels are enqueued (top layer
         first); None removes it.  The ctypes thunk is kept alive by the plan."""
+        if getattr(self, "_grad_cb_fn", None) is fn and (fn is None or getattr(self, "_grad_cb", None) is not None):
+            return                                  # unchanged since the last backward: keep the installed thunk
+        self._grad_cb_fn = fn
         self._grad_cb = GRAD_READY_FN(lambda _user, layer: fn(int(layer))) if fn is not None else None
         _check(load().csn_lstm_plan_set_grad_callback(self._plan, ctypes.cast(self._grad_cb, _c_void_p) if fn is not None
                                                       else None, None))
