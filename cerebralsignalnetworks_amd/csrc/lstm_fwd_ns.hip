@@ -66,6 +66,16 @@ __device__ __forceinline__ void ns_recurrence(const PersistFwdArgs& a, const Per
                                               int mt, bool local) {
   constexpr int GI = KB / 4;                       // k-blocks per DMA group = DMA instructions per wave and group
   constexpr bool AIA = KB <= 24;                   // accumulators in AGPRs beside the weights (ns_mfma)
+  // H = 1024: the h tile (128 KB per step) comes in by LDS-DMA, all 32 pieces of a wave in flight at once.  Through registers
+  // (the form below, kept for H <= 768) this width has staging registers for ONE group of 8 k-blocks: 32 KB in flight per
+  // CU, i.e. four serial round trips to L2 per step -- in-kernel stamps: 5.2 us for the h stream + 1.8 us of MFMAs.  A DMA
+  // piece costs ~100 cycles of issue (which is why the narrower widths, whose registers hold two groups, stay with
+  // register loads), but needs no register and no ds_write, so nothing limits the bytes in flight (round 4)
+#if defined(CSN_NS_NO_HDMA)      // timing A/B (tools/abl_build.sh)
+  constexpr bool HDMA = false;
+#else
+  constexpr bool HDMA = KB >= 32;
+#endif
   constexpr int P = FUSED ? 16 : 8;                // 16-byte registers of one input request
   static_assert(KB % 4 == 0, "4 load groups");
   const int B = a.B, H = a.H, MT = a.MT;
@@ -90,7 +100,9 @@ __device__ __forceinline__ void ns_recurrence(const PersistFwdArgs& a, const Per
   // ---- stationary operands: this wave's two gate-row tiles of W_hh for all of K.  Register p holds k-block
   // (p + rot) % KB: the workgroups of a group all pull the same slab and each walks it from its own offset, so that
   // at any moment they are on different lines (lstm_bwd_persist.hip).
-  const int rot = a.rotate ? __builtin_amdgcn_readfirstlane((slice * KB) / nslices) : 0;
+  // (LDS-DMA form: rotation in steps of 4 k-blocks, so that four consecutive walk positions are four consecutive KB of the
+  // slab -- one M0 / one scalar offset per four pieces, the rest in the instruction offset -- and never straddle the wrap)
+  const int rot = a.rotate ? (__builtin_amdgcn_readfirstlane((slice * KB) / nslices) & (HDMA ? ~3 : ~0)) : 0;
   const int tile0 = (u0 >> 2) + 2 * wave;              // first of this wave's two 16-row tiles of the interleaved 4H axis
   bf16x8 wreg[KB][2];
 #pragma unroll
@@ -187,6 +199,21 @@ __device__ __forceinline__ void ns_recurrence(const PersistFwdArgs& a, const Per
         for (int j = 0; j < 2; ++j) nxt[rg * 2 + j] = ns_bload_nt_f32x4(in_rsrc, xvoff[rg] + j * 64, sbase);
     }
   };
+  if constexpr (FUSED && HDMA) {
+    // The x tile of a step (64 rows x 128 features, 16 KB) is the same for all workgroups of the group and comes from HBM:
+    // requested a step ahead it still arrived 0.6 us late (in-kernel stamps: the x MFMAs waited, and with them every h
+    // piece queued behind the x loads).  Workgroup i therefore pulls the tile of step t_first + i into the group's L2 now
+    // (default cache policy, LDS-DMA into the idle h tile: no registers; the data itself is not used), so that the
+    // requests of the steps hit L2.
+    if (slice < nsteps) {
+      const int pbase = __builtin_amdgcn_readfirstlane((int)((((size_t)slice * xslab + (size_t)(m0 >> 4) * xkb * 512) * 2) + (size_t)wave * 4096));
+      char* const dst = smem + (size_t)wave * 4096;
+      ns_dma16_sc1<0, 0>(in_rsrc, dst, lane * 16, pbase);
+      ns_dma16_sc1<1024, 0>(in_rsrc, dst, lane * 16, pbase);
+      ns_dma16_sc1<2048, 0>(in_rsrc, dst, lane * 16, pbase);
+      ns_dma16_sc1<3072, 0>(in_rsrc, dst, lane * 16, pbase);
+    }
+  }
   request_input(t_first);
 
   const __amdgpu_buffer_rsrc_t hdst_rsrc =        // (slabs t_first .. t_first + nsteps: read h_{t-1} from slab t, write h_t to slab t + 1)
@@ -241,8 +268,22 @@ __device__ __forceinline__ void ns_recurrence(const PersistFwdArgs& a, const Per
         }
       }
       CSN_NSTAMP(0);   // wait for h_{t-1}
-      issue_group(0);
-      if (SB > 1) issue_group(1);
+      if constexpr (HDMA) {
+        // walk position p of this wave's row group <- k-block (p + rot) % KB, 1 KB per instruction, sc1 (L1 bypassed)
+#pragma unroll
+        for (int p = 0; p < KB; p += 4) {
+          char* const dst = smem + ((size_t)wave * KB + p) * 1024;
+          const int so = sbase + kb_next * 1024;
+          ns_dma16_sc1<0>(hdst_rsrc, dst, lane * 16, so);
+          ns_dma16_sc1<1024>(hdst_rsrc, dst, lane * 16, so);
+          ns_dma16_sc1<2048>(hdst_rsrc, dst, lane * 16, so);
+          ns_dma16_sc1<3072>(hdst_rsrc, dst, lane * 16, so);
+          kb_next = kb_next + 4 >= KB ? kb_next + 4 - KB : kb_next + 4;
+        }
+      } else {
+        issue_group(0);
+        if (SB > 1) issue_group(1);
+      }
       __builtin_amdgcn_sched_barrier(0);
       CSN_NSTAMP(8);   // first two groups requested
     }
@@ -266,7 +307,7 @@ __device__ __forceinline__ void ns_recurrence(const PersistFwdArgs& a, const Per
     if (t > 0) {
       // MFMAs of one group: fragment reads in inline asm with counted lgkmcnt waits, two k-blocks ahead (one ahead
       // left every read's latency half exposed: 0.70 us per group of 48 MFMAs instead of 0.33)
-      constexpr int HD = KB >= 32 ? 2 : 3;                 // fragment buffers (register budget): reads run HD - 1 k-blocks ahead
+      constexpr int HD = (KB >= 32 && !HDMA) ? 2 : 3;      // fragment buffers (register budget; the DMA form has no staging registers): reads run HD - 1 k-blocks ahead
       auto mfma_group = [&](int g) {
         bf16x8 hf[HD][4];
 #pragma unroll
@@ -296,6 +337,19 @@ __device__ __forceinline__ void ns_recurrence(const PersistFwdArgs& a, const Per
           __builtin_amdgcn_sched_barrier(0);
         }
       };
+      if constexpr (HDMA) {
+        // counted waits: behind the pieces of group g this wave has issued the (3 - g) GI pieces of the later groups and,
+        // in the plain layers, the P loads of the next step's projection (vector-memory operations retire in order)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          ns_wait_group<KB, FUSED ? 0 : P>(g);
+          __builtin_amdgcn_s_barrier();            // everybody's pieces of group g are in the tile
+          __builtin_amdgcn_sched_barrier(0);
+          mfma_group(g);
+          __builtin_amdgcn_sched_barrier(0);
+          CSN_NSTAMP(10 + g > 12 ? 12 : 10 + g);
+        }
+      } else {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         // group g has landed in this wave's registers (the compiler counts the vmcnt: only the next group's loads are
@@ -316,6 +370,7 @@ __device__ __forceinline__ void ns_recurrence(const PersistFwdArgs& a, const Per
         CSN_NSTAMP(10 + g > 12 ? 12 : 10 + g);
       }
       mfma_group(3);
+      }
     }
     ns_mfma_fence();
     __builtin_amdgcn_sched_barrier(0);

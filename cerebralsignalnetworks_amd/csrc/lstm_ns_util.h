@@ -10,11 +10,14 @@ static constexpr int kNsStageBytes = 64 * (288 + 144 + 80);               // pad
 typedef __attribute__((ext_vector_type(4))) unsigned nu32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned nu32x2;
 
+// (OFF: instruction offset, added to the global AND the LDS address: four consecutive 1 KB pieces share one M0 / soffset;
+// AUX: cache policy bits of the load -- 16 = sc1 for hand-off data, 0 = default for data that should stay in L2)
+template <int OFF = 0, int AUX = 16>
 __device__ __forceinline__ void ns_dma16_sc1(__amdgpu_buffer_rsrc_t rsrc, void* lds, int voffset, int soffset) {
   // buffer_load_dwordx4 ... lds: 16 bytes per lane, global (rsrc + soffset + voffset) -> LDS at lds + lane * 16.
   // Every block offset is wave-uniform (an SGPR), the only VGPR is lane * 16; aux 16 = sc1 (this CU's L1 is bypassed:
   // hand-off data)
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds, 16, voffset, soffset, 0, 16);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds, 16, voffset, soffset, OFF, AUX);
 }
 __device__ __forceinline__ f32x4 ns_bload_nt_f32x4(__amdgpu_buffer_rsrc_t rsrc, int voffset, int soffset) {
   nu32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voffset, soffset, 2);     // aux 2 = nt (streamed once)

@@ -90,8 +90,12 @@ def _write_report(name, obj):
 # bf16 path against the f64 fixture: 2 x the values measured on MI355X in round 3 (profiles/r03_parity_cfg*_bf16.json)
 # measured: cfg2 feat 1.55e-4, loss 6.0e-7, worst gradient 0.57 %; cfg4 feat 1.03e-4, loss 2.4e-6, worst gradient 0.62 %
 # (round 2's bounds were 3e-2 / 5e-3 / 6 %: 50 - 8000 x looser than what the kernels do)
+# cfg4's loss bound (round 4): the scalar loss error of the bf16 path moves with the ORDER of the float32 accumulation over K
+# -- 2.4e-6 (round 3), 5.0e-6 (layer-0 projection fused: its MFMAs now come first), 8.8e-6 (K walk rotated in steps of 4
+# k-blocks for the LDS-DMA pieces) for the same kernels' arithmetic; features and gradients do not move (1.0e-4, 0.6 %).
+# 2e-5 covers the orders seen with a factor 2 and is 5 x inside the north star's 1e-4.
 BF16_BOUNDS = {"cfg2": {"feat": 3.2e-4, "loss": 1.3e-6, "grad": 1.2e-2},
-               "cfg4": {"feat": 2.1e-4, "loss": 5.0e-6, "grad": 1.3e-2}}
+               "cfg4": {"feat": 2.1e-4, "loss": 2.0e-5, "grad": 1.3e-2}}
 
 
 @pytest.mark.parametrize("tag", ["cfg2", "cfg4"])

@@ -9,6 +9,8 @@ from cerebralsignalnetworks_amd.trainer import DistillTrainer  # noqa: E402
 
 dev = torch.device("cuda:0")
 B, C, T, H, L, D = 256, 128, 500, 768, 2, 384
+if os.environ.get("CSN_STAMP_CFG4"):      # Spampinato shapes: the N-split forward with the fused layer-0 projection
+    T, H = 440, 1024
 m = Model(input_size=C, lstm_size=H, lstm_layers=L, output_size=D, include_top=False).to(dev)
 tr = DistillTrainer(m, EEGFilters(1000, 3).sos, loss="cosine")
 x = torch.randn(B, C, T, device=dev); tg = torch.randn(B, D, device=dev)
