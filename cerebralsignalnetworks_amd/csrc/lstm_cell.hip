@@ -269,24 +269,38 @@ lstm_cell_fwd_ks_kernel(CellFwdBatch batch, int B, int H) {
     // each of its 16 rows; with the second half requested a phase later the line had left L1 again and crossed the
     // L2 -> CU fabric twice).  All loads unconditional (rows beyond B read row 0: their columns of the product are never
     // stored; a select on a loaded value puts a wait for the load right behind it).
-    const int kq = H >> 2, k_beg = wave * kq;
-#pragma unroll 2
-    for (int k0 = k_beg; k0 < k_beg + kq; k0 += 2 * F::kStep) {
-      typename F::type wf[2][4], hf[2][4];
+    const int kq = H >> 2, k_beg = wave * kq, n = kq / (2 * F::kStep);
+    // two stages: the lines of k-step i + 1 are requested before the MFMAs of k-step i (round 4; as one stage -- load, wait,
+    // multiply -- every k-step exposed its whole load latency: 24 us per cell at cfg2 against 10.7 us of f32 MFMA issue).
+    // Same k order, same sums.
+    typename F::type wf[2][2][4], hf[2][2][4];
+    auto load = [&](int b, int i) {
+      const int k0 = k_beg + i * 2 * F::kStep;
 #pragma unroll
       for (int hfl = 0; hfl < 2; ++hfl) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) wf[hfl][g] = F::load(wrow[g], k0 + hfl * F::kStep, lane);
+        for (int g = 0; g < 4; ++g) wf[b][hfl][g] = F::load(wrow[g], k0 + hfl * F::kStep, lane);
 #pragma unroll
-        for (int rg = 0; rg < 4; ++rg) hf[hfl][rg] = F::load(hrow[rg], k0 + hfl * F::kStep, lane);
+        for (int rg = 0; rg < 4; ++rg) hf[b][hfl][rg] = F::load(hrow[rg], k0 + hfl * F::kStep, lane);
       }
+    };
+    auto mma = [&](int b) {
 #pragma unroll
       for (int hfl = 0; hfl < 2; ++hfl)
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg)
 #pragma unroll
-          for (int g = 0; g < 4; ++g) acc[rg][g] = F::mma(wf[hfl][g], hf[hfl][rg], acc[rg][g]);
+          for (int g = 0; g < 4; ++g) acc[rg][g] = F::mma(wf[b][hfl][g], hf[b][hfl][rg], acc[rg][g]);
+    };
+    load(0, 0);
+    int i = 0;
+    for (; i + 2 <= n; i += 2) {
+      load(1, i + 1);
+      mma(0);
+      load(0, i + 2 < n ? i + 2 : n - 1);          // (the last one is a harmless re-request of the final lines)
+      mma(1);
     }
+    if (i < n) mma(0);
   }
 #pragma unroll
   for (int rg = 0; rg < 4; ++rg)
