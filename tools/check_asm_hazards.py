@@ -109,7 +109,7 @@ def parse(path):
             continue
         if not s or s.startswith(";"):
             continue
-        m = re.match(r"^([A-Za-z_][\w.$]*):", raw)
+        m = re.match(r"^([.A-Za-z_][\w.$]*):", raw)
         if m and not raw[0].isspace():
             if not m.group(1).startswith(".L"):
                 name = m.group(1)
