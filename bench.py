@@ -370,14 +370,17 @@ def main():
             flops_per_launch = 2.0 * B * 4 * H * H * cells_per_launch
             bytes_per_cell = B * H * (24.0 if dom == "bwd" else 30.0)
             bytes_per_launch = bytes_per_cell * cells_per_launch
-            fused_x = (dom == "fwd" and persist["fwd"] and C == 128 and H != 512 and not os.environ.get("CSN_NO_FUSE_X"))
+            fused_fwd = persist["fwd"] and C == 128 and H != 512 and not os.environ.get("CSN_NO_FUSE_X")
+            fused_x = dom == "fwd" and fused_fwd
             if fused_x:
                 # layer 0 multiplies x_t itself (make_layout's fuse_x in lstm.hip): its cells read x (bf16, C per row) instead of
                 # a float32 projection (4H per row) and carry the projection's flops; 1 / L of a launch's cells are layer 0's
                 share0 = cells_per_launch / L
                 bytes_per_launch += share0 * B * (2.0 * C - 16.0 * H)
                 flops_per_launch += share0 * 2.0 * B * 4 * H * C
-            beside = dom == "bwd" and persist["bwd"] and L > 1 and not os.environ.get("CSN_NO_BESIDE")
+            # (lstm.hip:backward_persist's own condition: the launch has idle workgroups only while a group is <= 28 slices
+            #  of 32 units, i.e. H <= 896 -- at H = 1024 the 8 groups fill all 256 CUs and the GEMM is a kernel of its own)
+            beside = (dom == "bwd" and persist["bwd"] and 1 < L <= 4 and H // 32 <= 28 and not os.environ.get("CSN_NO_BESIDE"))
             if beside:
                 # the backward launches also carry the input-gradient GEMMs of the layers above layer 0 on their idle
                 # workgroups: dx[T*B, H] = dgates[T*B, 4H] W_ih -> 2*T*B*4H*H flops, read dgates bf16, write dx f32
@@ -429,7 +432,7 @@ def main():
                                                   "frac": (ach_tf / peak) if hbm_bound else (ach_gb / HBM_PEAK_GBS)},
                                "us_per_launch": us, "launches": {k: pr[k + "_launches"] for k in ("fwd", "bwd")},
                                "cells_per_launch": cells_per_launch, "input_gradient_gemm_in_launch": bool(beside),
-                               "layer0_projection_in_launch": bool(fused_x),
+                               "layer0_projection_in_launch": bool(fused_x), "layer0_projection_in_forward_launch": bool(fused_fwd),
                                "note": "recurrent GEMM chain with one hand-off between workgroups per timestep; neither "
                                        "roofline binds: the step is paced by the per-step operand stream from L2 and "
                                        "the hand-off latency (DESIGN.md section 3)"}

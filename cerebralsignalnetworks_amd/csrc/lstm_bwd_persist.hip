@@ -333,8 +333,10 @@ __global__ void __launch_bounds__(256) lstm_bwd_persist_kernel(PersistBwdArgs a)
         }
 #ifdef CSN_SLAB_TAGS
         bool stale = false;       // (debug library, see lstm_fwd_persist.hip: a non-sentinel piece with the wrong step tag)
-        int stale_kb = -1;
-        unsigned stale_u0 = 0;
+#ifdef CSN_SLAB_TAGS_DUMP         // where the first stale piece was seen (CSN_TAGS_VERBOSE): a dozen values kept live across the unrolled
+        int stale_kb = -1;        // k-block loop -- with them the H = 768 / 1024 instantiations of the tags build spilled 488 / 868
+        unsigned stale_u0 = 0;    // bytes per lane, which the spill gate (now applied to that build too) does not allow; opt-in
+#endif
 #endif
 #pragma unroll
         for (int kb = 0; kb < KS; ++kb) {
@@ -345,7 +347,9 @@ __global__ void __launch_bounds__(256) lstm_bwd_persist_kernel(PersistBwdArgs a)
             for (int rg = 0; rg < 4; ++rg) {
               const u32x4 u = __builtin_bit_cast(u32x4, df[kb % RING][rg]);
               const bool bad = u[0] != 0xffffffffu && (u[0] & 1u) != want;
+#ifdef CSN_SLAB_TAGS_DUMP
               if (bad && stale_kb < 0) { stale_kb = kb * 4 + rg; stale_u0 = u[0]; }
+#endif
               stale |= bad;
             }
           }
@@ -363,6 +367,7 @@ __global__ void __launch_bounds__(256) lstm_bwd_persist_kernel(PersistBwdArgs a)
         }
 #ifdef CSN_SLAB_TAGS
         if (__any(stale) && lane == 0) __hip_atomic_store(a.error_flag + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef CSN_SLAB_TAGS_DUMP
         if (stale) {     // first detection of the workspace: where it was (read back by csn_lstm_status_read of the debug library)
           if (atomicCAS(a.error_flag + 7, 0u, 1u) == 0u) {
             unsigned* dbg = a.error_flag + 8;
@@ -372,6 +377,7 @@ __global__ void __launch_bounds__(256) lstm_bwd_persist_kernel(PersistBwdArgs a)
             dbg[14] = __builtin_amdgcn_s_getreg(6164) & 7u; dbg[15] = (unsigned)__popcll(__ballot(stale));
           }
         }
+#endif
 #endif
         again = false;
         if constexpr (dpoll) {

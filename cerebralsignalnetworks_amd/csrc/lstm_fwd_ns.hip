@@ -220,15 +220,37 @@ __device__ __forceinline__ void ns_recurrence(const PersistFwdArgs& a, const Per
       __builtin_amdgcn_make_buffer_rsrc((void*)ns_uniform(S.h_blk_all + (size_t)t_first * slab), 0,
                                         __builtin_amdgcn_readfirstlane((int)((size_t)(nsteps + 1) * slab * 2)), 0x00020000);
 
-  for (int s = 0; s < nsteps; ++s) {
-    const int t = t_first + s;
-    f32x4 acc[4][2];
+  // Fused layer 0: the sum of a step starts from bias + x_t W_ih^T, and that part does not depend on h_{t-1} -- it is computed
+  // at the END of the step before, behind the publish, i.e. in the time the workgroup would spend waiting for its neighbours'
+  // h anyway (round 4: in-kernel stamps had the x MFMAs and their wait on the critical path of the slower layer of every
+  // launch).  Same terms in the same order as before (bias, x k-blocks 0..3, then h): same bits.
+  f32x4 acc[4][2];
+  auto start_from_x = [&]() {
 #pragma unroll
     for (int rg = 0; rg < 4; ++rg)
 #pragma unroll
-      for (int j = 0; j < 2; ++j)            // plain: the sum starts from the input projection; fused: from the bias
-        acc[rg][j] = FUSED ? *reinterpret_cast<const f32x4*>(bias_lds + j * 4 * 288) : nxt[rg * 2 + j];
+      for (int j = 0; j < 2; ++j) acc[rg][j] = *reinterpret_cast<const f32x4*>(bias_lds + j * 4 * 288);
     ns_mfma_fence();
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) ns_mfma<AIA, !AIA>(acc[rg][j], wih[FUSED ? kb : 0][j], __builtin_bit_cast(bf16x8, nxt[FUSED ? rg * 4 + kb : 0]));
+    ns_mfma_fence();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  if constexpr (FUSED) start_from_x();        // (the launch's first step: the one place that waits for x)
+
+  for (int s = 0; s < nsteps; ++s) {
+    const int t = t_first + s;
+    if constexpr (!FUSED) {
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[rg][j] = nxt[rg * 2 + j];      // plain: the sum starts from the input projection
+      ns_mfma_fence();
+    }
 
     // LDS address of this lane's 16 bytes in block 0; the opaque zero is re-made every step so that the 4 KB fragment
     // addresses derived from it stay one add each instead of being hoisted into 4 KB registers for good
@@ -287,17 +309,7 @@ __device__ __forceinline__ void ns_recurrence(const PersistFwdArgs& a, const Per
       __builtin_amdgcn_sched_barrier(0);
       CSN_NSTAMP(8);   // first two groups requested
     }
-    if constexpr (FUSED) {
-      // x_t W_ih^T from the registers requested a step ago, while the h loads are in flight
-#pragma unroll
-      for (int kb = 0; kb < 4; ++kb)
-#pragma unroll
-        for (int rg = 0; rg < 4; ++rg)
-#pragma unroll
-          for (int j = 0; j < 2; ++j) ns_mfma<AIA, !AIA>(acc[rg][j], wih[kb][j], __builtin_bit_cast(bf16x8, nxt[rg * 4 + kb]));
-      __builtin_amdgcn_sched_barrier(0);
-      CSN_NSTAMP(9);   // x MFMAs
-    } else {
+    if constexpr (!FUSED) {
       // plain layers: the next step's projection (8 registers) is requested now, behind the first h loads, and has the
       // whole step to arrive from HBM
       request_input(s + 1 < nsteps ? t + 1 : t);
@@ -307,7 +319,8 @@ __device__ __forceinline__ void ns_recurrence(const PersistFwdArgs& a, const Per
     if (t > 0) {
       // MFMAs of one group: fragment reads in inline asm with counted lgkmcnt waits, two k-blocks ahead (one ahead
       // left every read's latency half exposed: 0.70 us per group of 48 MFMAs instead of 0.33)
-      constexpr int HD = (KB >= 32 && !HDMA) ? 2 : 3;      // fragment buffers (register budget; the DMA form has no staging registers): reads run HD - 1 k-blocks ahead
+      // (the fused body at H = 1024 keeps two: with three it is no faster, and its registers are the tightest of the library)
+      constexpr int HD = (KB >= 32 && (!HDMA || FUSED)) ? 2 : 3;      // fragment buffers (register budget; the DMA form has no staging registers): reads run HD - 1 k-blocks ahead
       auto mfma_group = [&](int g) {
         bf16x8 hf[HD][4];
 #pragma unroll
@@ -376,7 +389,7 @@ __device__ __forceinline__ void ns_recurrence(const PersistFwdArgs& a, const Per
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (FUSED) {
       // (fused layer 0: the 64 registers of x are free only now; requested later than this -- after the gate math --
-      // the HBM latency of x showed up in front of the next step's x MFMAs)
+      // its latency lands in the publish's store drain, i.e. in front of the flag: measured twice, rounds 2 and 4)
       request_input(s + 1 < nsteps ? t + 1 : t);
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -452,6 +465,10 @@ __device__ __forceinline__ void ns_recurrence(const PersistFwdArgs& a, const Per
       else __hip_atomic_store(fl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     CSN_NSTAMP(5);     // signal
+    if constexpr (FUSED) {
+      if (s + 1 < nsteps) start_from_x();      // bias + x_{t+1} W_ih^T: x_{t+1} was requested behind this step's MFMAs, the drain above covered it
+      CSN_NSTAMP(9);   // x MFMAs of the next step
+    }
   }
 }
 

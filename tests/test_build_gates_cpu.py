@@ -77,3 +77,44 @@ def test_spill_gate_reads_the_compilers_remarks(tmp_path):
     good = tmp_path / "g.res"
     good.write_text("\n".join(res.read_text().splitlines()[:4]) + "\n")
     assert sp.main([str(good)]) == 0
+
+
+def _res(tmp_path, name, fn, scratch, spill, fmt):
+    rows = [f"Function Name: {fn}", "    VGPRs: 256", f"    ScratchSize [bytes/lane]: {scratch}", f"    VGPRs Spill: {spill}"]
+    tag = " [-Rpass-analysis=kernel-resource-usage]"
+    text = "".join((f"x.hip:3:0: remark: {r}{tag}\n" if fmt == "plain" else f"remark: x.hip:3:0: {r}{tag}\n") for r in rows)
+    p = tmp_path / name
+    p.write_text(text)
+    return str(p)
+
+
+def test_spill_gate_reads_both_remark_formats_and_refuses_what_it_cannot_read(tmp_path):
+    # (-save-temps, the Makefile's form since round 4, moves the word "remark" in front of the location: the round-3 parser
+    #  matched nothing in that form and passed every build -- the gate had been off for part of round 4)
+    for fmt in ("plain", "savetemps"):
+        assert sp.main([_res(tmp_path, f"ok_{fmt}.res", "_Z1av", 0, 0, fmt)]) == 0
+        assert sp.main([_res(tmp_path, f"bad_{fmt}.res", "_Z1bv", 488, 122, fmt)]) == 1
+        assert sp.parse(_res(tmp_path, f"p_{fmt}.res", "_Z1cv", 8, 2, fmt))["_Z1cv"] == {"VGPRs": 256, "ScratchSize [bytes/lane]": 8, "VGPRs Spill": 2}
+    # a function whose figures are missing (a format this parser does not know) fails the build instead of passing it
+    unread = tmp_path / "u.res"
+    unread.write_text("remark: x.hip:3:0: Function Name: _Z1dv [-Rpass-analysis=kernel-resource-usage]\nremark: x.hip:3:0:     Scratch bytes per lane = 0\n")
+    assert sp.main([str(unread)]) == 1
+
+
+def test_spill_gate_passes_whole_scalar_spills_only(tmp_path):
+    """The compiler bug the gate exists for is a spilled TUPLE split between scratch and an AGPR ('Reload Reuse').  Whole
+    single-dword spills pass with a note -- but only when the ISA listing next to the remarks proves that this is all there is."""
+    fn = "_Z1kv"
+
+    def case(name, isa):
+        res = _res(tmp_path, name + ".res", fn, 8, 1, "savetemps")
+        if isa is not None:
+            (tmp_path / (name + "-hip-amdgcn-amd-amdhsa-gfx950.s")).write_text("\t.text\n" + fn + ":\n" + textwrap.dedent(isa) + "\ts_endpgm\n.Lfunc_end0:\n")
+        return sp.main([res])
+
+    scalar = "\tscratch_store_dword off, v69, off       ; 4-byte Folded Spill\n\tscratch_load_dword v69, off, off        ; 4-byte Folded Reload\n"
+    assert case("scalar", scalar) == 0
+    assert case("nolisting", None) == 1
+    assert case("tuple", scalar + "\tscratch_store_dwordx3 off, v[38:40], off ; 12-byte Folded Spill\n") == 1
+    assert case("reuse", scalar + "\tv_accvgpr_write_b32 a225, v41 ; Reload Reuse\n") == 1
+    assert case("wide_load", scalar + "\tscratch_load_dwordx4 v[4:7], off, off offset:16\n") == 1
