@@ -369,8 +369,14 @@ def main():
             #   HBM bytes, forward : read the input projection (f32 4H), write gates (bf16 4H) + c (f32 H) + h (bf16 H)
             flops_per_launch = 2.0 * B * 4 * H * H * cells_per_launch
             bytes_per_cell = B * H * (24.0 if dom == "bwd" else 30.0)
+            f32_ws = args.dtype != "bf16" and persist[dom]
+            if f32_ws:
+                # float32 weight-stationary recurrence (lstm_f32_persist.hip), per (row, unit) and step:
+                #   backward: read gates 16 + c, c_prev, dy 12, write dgates row-major 16 + fragment-major 16 = 60 bytes
+                #   forward : read the projection 16, write gates 16 + c 4 + h row-major 4 + fragment-major 4 = 44 bytes
+                bytes_per_cell = B * H * (60.0 if dom == "bwd" else 44.0)
             bytes_per_launch = bytes_per_cell * cells_per_launch
-            fused_fwd = persist["fwd"] and C == 128 and H != 512 and not os.environ.get("CSN_NO_FUSE_X")
+            fused_fwd = args.dtype == "bf16" and persist["fwd"] and C == 128 and H != 512 and not os.environ.get("CSN_NO_FUSE_X")
             fused_x = dom == "fwd" and fused_fwd
             if fused_x:
                 # layer 0 multiplies x_t itself (make_layout's fuse_x in lstm.hip): its cells read x (bf16, C per row) instead of
@@ -380,7 +386,8 @@ def main():
                 flops_per_launch += share0 * 2.0 * B * 4 * H * C
             # (lstm.hip:backward_persist's own condition: the launch has idle workgroups only while a group is <= 28 slices
             #  of 32 units, i.e. H <= 896 -- at H = 1024 the 8 groups fill all 256 CUs and the GEMM is a kernel of its own)
-            beside = (dom == "bwd" and persist["bwd"] and 1 < L <= 4 and H // 32 <= 28 and not os.environ.get("CSN_NO_BESIDE"))
+            beside = (args.dtype == "bf16" and dom == "bwd" and persist["bwd"] and 1 < L <= 4 and H // 32 <= 28
+                      and not os.environ.get("CSN_NO_BESIDE"))
             if beside:
                 # the backward launches also carry the input-gradient GEMMs of the layers above layer 0 on their idle
                 # workgroups: dx[T*B, H] = dgates[T*B, 4H] W_ih -> 2*T*B*4H*H flops, read dgates bf16, write dx f32
@@ -461,10 +468,13 @@ def main():
             torch.cuda.synchronize()
             dt32 = (time.perf_counter() - t1) / 10
             # floor of ANY exact-f32 MFMA path: the step's 22.4 GFLOP / segment at the 157.3 TFLOP/s f32 matrix peak
+            k32 = t32.model.lstm.all_plans()[0].kernel_names()
             res["f32_path"] = {"value": B / dt32, "unit": "segments/s", "ms_per_step": 1e3 * dt32, "steps": 10,
-                               "mfma_f32_floor_ms": 1e3 * B * flops_per_seg / 157.3e12,
-                               "note": "compute_dtype=float32: exact-f32 MFMA (v_mfma_f32_16x16x4_f32), per-step K-split cell "
-                                       "kernels + generic GEMMs: the path that holds every gradient to 1e-4 (parity path)"}
+                               "mfma_f32_floor_ms": 1e3 * B * flops_per_seg / 157.3e12, "recurrence_kernels": list(k32),
+                               "note": "compute_dtype=float32: exact-f32 MFMA (v_mfma_f32_16x16x4_f32), " +
+                                       ("weight-stationary recurrence, one launch per layer" if "persist" in k32[0]
+                                        else "per-step K-split cell kernels") +
+                                       " + generic GEMMs: the path that holds every gradient to 1e-4 (parity path)"}
             del m32, t32
         if world == 1 and not args.no_cpu_baseline:
             from oracle import cpu_path, eeg_filter

@@ -28,6 +28,7 @@
 
 #include "csn_common.h"
 #include "lstm_cell_blk.h"
+#include "lstm_f32_persist.h"
 
 namespace csn {
 
@@ -49,7 +50,14 @@ struct WsLayout {
   bool fuse_x;
   bool il, persist, persist_bwd;
   bool fwd_ns;             // forward runs the N-split kernel (lstm_fwd_ns.hip), else the K-split one
+  bool f32_persist;        // exact-float32 path: weight-stationary recurrence (lstm_f32_persist.hip), one launch per layer and row block
 };
+
+static bool whole_chip() {       // (asked when a layout is made -- plan creation --, not per launch)
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return false;
+  return hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus >= 256;
+}
 
 static WsLayout make_layout(const csnLstmDesc& d, int training, const Options& opt) {
   WsLayout w{};
@@ -117,6 +125,22 @@ static WsLayout make_layout(const csnLstmDesc& d, int training, const Options& o
     w.wih0_blk = take(G * d.I * 2);
   }
   if (w.persist_bwd) w.zeros_bh = take((size_t)d.B * H * 4);
+  // exact-float32 path, weight-stationary: needs a whole MI355X like the bf16 kernels (all workgroups of a launch co-resident)
+  w.f32_persist = !w.il && d.dtype == CSN_F32 && !opt.no_persist && !opt.cell_v1 && f32_persist_supported(d.B, d.H) && whole_chip();
+  if (w.f32_persist) {
+    const size_t MTt = Bpad / 64;
+    w.zero_fwd = off;
+    for (int l = 0; l < d.L; ++l) w.layer[l].counters = take(((size_t)d.T + 1) * MTt * kF32FlagLine * 4);
+    w.zero_fwd_bytes = off - w.zero_fwd;
+    for (int l = 0; l < d.L; ++l) w.layer[l].h_blk_all = take(((size_t)d.T + 1) * Bpad * H * 4);       // fragment-major hand-off copies
+    if (training) {
+      for (int l = 0; l < d.L; ++l) w.layer[l].dg_blk_all = take((size_t)d.T * Bpad * G * 4);
+      w.zeros_bh = take((size_t)d.B * H * 4);
+      w.zero_bwd = off;
+      for (int l = 0; l < d.L; ++l) w.layer[l].bflags = take((size_t)d.T * MTt * kF32FlagLine * 4);
+      w.zero_bwd_bytes = off - w.zero_bwd;
+    }
+  }
   if (w.persist) {
     w.zero_fwd = off;
     // (x 4: the wave-specialised forward body keeps one flag line per 16-row chain, the half-pipelined one per 32-row half)
@@ -354,6 +378,7 @@ static bool bwd_grouped(const csnLstmPlan* P) {
 extern "C" const char* csn_lstm_plan_kernel_name(const csnLstmPlan* P, int which) {
   if (P == nullptr) return nullptr;
   const bool ks = (P->d.dtype == CSN_F32 ? P->d.H % 128 == 0 : P->d.H % 256 == 0);      // K-split cell kernels (lstm_cell.hip)
+  if (P->w.f32_persist) return which == 0 ? "lstm_fwd_f32_persist_kernel" : (which == 1 ? "lstm_bwd_f32_persist_kernel" : nullptr);
   if (which == 0) {
     if (P->w.fwd_ns) return P->opt.fwd_ws && P->d.H == 768 ? "lstm_fwd_ws_kernel" : "lstm_fwd_ns_kernel";
     if (P->w.persist) return "lstm_fwd_persist_kernel";
@@ -424,7 +449,8 @@ extern "C" int csn_lstm_workspace_init(const csnLstmPlan* P, void* workspace, cs
     CSN_HIP_CHECK(hipMemsetAsync(ws + w.layer[l].h_all, 0, (size_t)P->d.B * P->d.H * es, st));
     CSN_HIP_CHECK(hipMemsetAsync(ws + w.layer[l].c_all, 0, (size_t)P->d.B * P->d.H * 4, st));
   }
-  if (w.persist_bwd) CSN_HIP_CHECK(hipMemsetAsync(ws + w.zeros_bh, 0, (size_t)P->d.B * P->d.H * 4, st));
+  if (w.persist_bwd || (w.f32_persist && P->training))
+    CSN_HIP_CHECK(hipMemsetAsync(ws + w.zeros_bh, 0, (size_t)P->d.B * P->d.H * 4, st));
   return CSN_OK;
 }
 
@@ -600,6 +626,131 @@ static int backward_v1(Plan& P, char* ws, const float* dy_last, const float* dy_
   if (dx) {
     const LayerWs& L = w.layer[0];
     if ((rc = gemm_nt(ws + L.dgates, ws + L.wiht, nullptr, ws + L.dx, TB, d->I, G, dt, CSN_F32, 0, st, P.opt))) return rc;
+    tb_to_bt_kernel<<<grid_for(TB * d->I), 256, 0, st>>>((const float*)(ws + L.dx), dx, B, T, d->I);
+    CSN_LAUNCH_CHECK();
+  }
+  return CSN_OK;
+}
+
+// Exact-float32 path, weight-stationary (lstm_f32_persist.hip): layer after layer, ONE recurrence launch per layer and
+// block of M-tiles, the non-recurrent contractions as whole-sequence GEMMs between them (the same GEMM kernels, the same
+// K order per output element as the chunked calls of forward_v1: row chunking does not enter a row's sum).
+static int forward_f32p(Plan& P, char* ws, const float* x, int64_t xsb, int64_t xst,
+                        const float* const* w_ih, const float* const* w_hh, const float* const* b_ih,
+                        const float* const* b_hh, int training, csnStream_t stream) {
+  const csnLstmDesc* d = &P.d;
+  const WsLayout& w = P.w;
+  Prof& g_prof = P.prof;
+  hipStream_t st = as_stream(stream);
+  const int B = d->B, T = d->T, H = d->H, NL = d->L;
+  const int64_t G = 4 * (int64_t)H, TB = (int64_t)T * B;
+  const int MTt = (B + 63) / 64, per = f32_persist_tiles_per_launch(H);
+  int rc;
+  if ((rc = launch_cast_strided(x, xsb, xst, B, T, d->I, ws + w.x_c, CSN_F32, st))) return rc;
+  for (int l = 0; l < NL; ++l) {
+    const LayerWs& L = w.layer[l];
+    const int64_t I = l == 0 ? d->I : H;
+    if ((rc = launch_cast(w_ih[l], ws + L.wih, G * I, CSN_F32, st))) return rc;
+    if ((rc = launch_cast(w_hh[l], ws + L.whh, G * H, CSN_F32, st))) return rc;
+    if (training) {
+      if ((rc = launch_transpose_cast(w_hh[l], G, H, ws + L.whht, CSN_F32, st))) return rc;
+      if ((rc = launch_transpose_cast(w_ih[l], G, I, ws + L.wiht, CSN_F32, st))) return rc;
+    }
+    if ((rc = launch_add_vec(b_ih[l], b_hh[l], (float*)(ws + L.bias), G, st))) return rc;
+    CSN_HIP_CHECK(hipMemsetAsync(ws + L.h_all, 0, (size_t)B * H * 4, st));
+    CSN_HIP_CHECK(hipMemsetAsync(ws + L.c_all, 0, (size_t)B * H * 4, st));
+  }
+  CSN_HIP_CHECK(hipMemsetAsync(ws + w.zero_fwd, 0, w.zero_fwd_bytes, st));      // the flag lines of every layer
+  int n_launch = 0;
+  if ((rc = prof_mark(g_prof, 0, st))) return rc;
+  for (int l = 0; l < NL; ++l) {
+    const LayerWs& L = w.layer[l];
+    const void* inp = l == 0 ? (const void*)(ws + w.x_c) : (const void*)(ws + w.layer[l - 1].h_all + (size_t)B * H * 4);
+    if ((rc = gemm_nt(inp, ws + L.wih, (const float*)(ws + L.bias), ws + L.xproj, TB, G, l == 0 ? d->I : H, CSN_F32, CSN_F32, 0, st, P.opt)))
+      return rc;
+    F32PersistFwdArgs a{};
+    a.w_hh = (const float*)(ws + L.whh);
+    a.xproj = (const float*)(ws + L.xproj);
+    a.gates = training ? (float*)(ws + L.gates) : nullptr;
+    a.c_all = (float*)(ws + L.c_all);
+    a.h_all = (float*)(ws + L.h_all);
+    a.h_blk = (float*)(ws + L.h_blk_all);
+    a.flags = (unsigned*)(ws + L.counters);
+    a.error_flag = (unsigned*)(ws + w.status);
+    a.B = B; a.T = T; a.MT_total = MTt;
+    for (int m = 0; m < MTt; m += per) {
+      a.mt0 = m;
+      a.MT = MTt - m < per ? MTt - m : per;
+      if ((rc = prof_pair(g_prof, 0, false, st))) return rc;
+      if ((rc = launch_fwd_f32_persist(a, H, st))) return rc;
+      if ((rc = prof_pair(g_prof, 0, true, st))) return rc;
+      ++n_launch;
+    }
+  }
+  if ((rc = prof_mark(g_prof, 1, st))) return rc;
+  g_prof.launches[0] = n_launch;
+  g_prof.cells[0] = T * NL;
+  g_prof.have[0] = g_prof.on;
+  return CSN_OK;
+}
+
+static int backward_f32p(Plan& P, char* ws, const float* dy_last, const float* dy_tm,
+                         float* const* dw_ih, float* const* dw_hh, float* const* db_ih, float* const* db_hh, float* dx,
+                         csnStream_t stream) {
+  const csnLstmDesc* d = &P.d;
+  const WsLayout& w = P.w;
+  Prof& g_prof = P.prof;
+  hipStream_t st = as_stream(stream);
+  const int B = d->B, T = d->T, H = d->H, NL = d->L;
+  const int64_t G = 4 * (int64_t)H, TB = (int64_t)T * B;
+  const int MTt = (B + 63) / 64, per = f32_persist_tiles_per_launch(H);
+  int rc;
+  CSN_HIP_CHECK(hipMemsetAsync(ws + w.zero_bwd, 0, w.zero_bwd_bytes, st));
+  int n_launch = 0;
+  if ((rc = prof_mark(g_prof, 2, st))) return rc;
+  for (int l = NL - 1; l >= 0; --l) {
+    const LayerWs& L = w.layer[l];
+    const bool top = (l == NL - 1);
+    F32PersistBwdArgs a{};
+    a.w_hh_t = (const float*)(ws + L.whht);
+    a.gates = (const float*)(ws + L.gates);
+    a.c_all = (const float*)(ws + L.c_all);
+    a.dy = top ? dy_tm : (const float*)(ws + w.layer[l + 1].dx);
+    a.dy_last = (top && dy_tm == nullptr) ? dy_last : nullptr;
+    a.zeros = (const float*)(ws + w.zeros_bh);
+    a.dgates = (float*)(ws + L.dgates);
+    a.dg_blk = (float*)(ws + L.dg_blk_all);
+    a.flags = (unsigned*)(ws + L.bflags);
+    a.error_flag = (unsigned*)(ws + w.status);
+    a.B = B; a.T = T; a.MT_total = MTt;
+    for (int m = 0; m < MTt; m += per) {
+      a.mt0 = m;
+      a.MT = MTt - m < per ? MTt - m : per;
+      if ((rc = prof_pair(g_prof, 1, false, st))) return rc;
+      if ((rc = launch_bwd_f32_persist(a, H, st))) return rc;
+      if ((rc = prof_pair(g_prof, 1, true, st))) return rc;
+      ++n_launch;
+    }
+    // gradient w.r.t. this layer's input = dy of the layer below, whole sequence
+    if (l > 0 && (rc = gemm_nt(ws + L.dgates, ws + L.wiht, nullptr, ws + L.dx, TB, H, G, CSN_F32, CSN_F32, 0, st, P.opt))) return rc;
+  }
+  if ((rc = prof_mark(g_prof, 3, st))) return rc;
+  g_prof.launches[1] = n_launch;
+  g_prof.cells[1] = T * NL;
+  g_prof.have[1] = g_prof.on;
+  for (int l = NL - 1; l >= 0; --l) {
+    const LayerWs& L = w.layer[l];
+    const int64_t I = l == 0 ? d->I : H;
+    const void* inp = l == 0 ? (const void*)(ws + w.x_c) : (const void*)(ws + w.layer[l - 1].h_all + (size_t)B * H * 4);
+    if ((rc = gemm_tn_full(ws + L.dgates, ws + L.h_all, dw_hh[l], G, H, TB, CSN_F32, ws + w.tn_scratch, st, P.opt))) return rc;
+    if ((rc = gemm_tn_full(ws + L.dgates, inp, dw_ih[l], G, I, TB, CSN_F32, ws + w.tn_scratch, st, P.opt))) return rc;
+    if ((rc = launch_colsum(ws + L.dgates, TB, G, CSN_F32, db_ih[l], ws + w.colsum, st))) return rc;
+    CSN_HIP_CHECK(hipMemcpyAsync(db_hh[l], db_ih[l], (size_t)G * 4, hipMemcpyDeviceToDevice, st));
+    P.grads_ready(l);
+  }
+  if (dx) {
+    const LayerWs& L = w.layer[0];
+    if ((rc = gemm_nt(ws + L.dgates, ws + L.wiht, nullptr, ws + L.dx, TB, d->I, G, CSN_F32, CSN_F32, 0, st, P.opt))) return rc;
     tb_to_bt_kernel<<<grid_for(TB * d->I), 256, 0, st>>>((const float*)(ws + L.dx), dx, B, T, d->I);
     CSN_LAUNCH_CHECK();
   }
@@ -1273,6 +1424,8 @@ extern "C" int csn_lstm_forward(csnLstmPlan* Pp, const float* x, int64_t x_strid
   // csn_lstm_status_clear, so a check at the end of an epoch / a timed region covers every step in it)
   if (w.il)
     rc = forward_il(P, ws, x, x_stride_b, x_stride_t, w_ih, w_hh, b_ih, b_hh, training, stream);
+  else if (w.f32_persist)
+    rc = forward_f32p(P, ws, x, x_stride_b, x_stride_t, w_ih, w_hh, b_ih, b_hh, training, stream);
   else
     rc = forward_v1(P, ws, x, x_stride_b, x_stride_t, w_ih, w_hh, b_ih, b_hh, training, stream);
   if (rc) return rc;
@@ -1323,5 +1476,6 @@ extern "C" int csn_lstm_backward(csnLstmPlan* Pp, const float* dy_last, const fl
     dy_tm = buf;
   }
   if (w.il) return backward_il(P, ws, dy_last, dy_tm, dw_ih, dw_hh, db_ih, db_hh, dx, stream);
+  if (w.f32_persist) return backward_f32p(P, ws, dy_last, dy_tm, dw_ih, dw_hh, db_ih, db_hh, dx, stream);
   return backward_v1(P, ws, dy_last, dy_tm, dw_ih, dw_hh, db_ih, db_hh, dx, stream);
 }

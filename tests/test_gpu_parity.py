@@ -1102,3 +1102,57 @@ def test_handoffs_identical_under_uneven_load(cuda):
         for a, b in zip(out, ref):
             assert torch.equal(a, b), f"repetition {rep}: outputs differ under load"
 
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,T,C,H,L", [(256, 24, 128, 768, 2),      # the benchmark width, all four M-tiles (192 workgroups)
+                                       (70, 37, 24, 128, 3),        # ragged last tile, 8 slices, three layers
+                                       (130, 21, 16, 512, 2), (64, 18, 128, 1024, 2), (5, 9, 8, 384, 1), (33, 1, 8, 256, 2),
+                                       (400, 6, 16, 768, 1)])      # 7 M-tiles at 48 slices: two launches per layer (5 + 2 tiles)
+def test_f32_weight_stationary_recurrence(cuda, B, T, C, H, L):
+    """The exact-float32 path's weight-stationary kernels (lstm_f32_persist.hip, one launch per layer) against the float64
+    oracle AND against the per-step launches they replace (CSN_NO_PERSIST): the forward keeps the operand map, the k order and
+    the order of the K-quarter partial sums of lstm_cell_fwd_ks_kernel, so its outputs are the same BITS; the backward groups
+    K = 4H into four partial sums where the per-step kernel uses eight -- agreement to float32 rounding."""
+    rng = np.random.default_rng(B * T + H)
+    p = lstm.init_params(C, H, L, 8, None, seed=5)
+    lp = {k[len("lstm."):]: v for k, v in p.items() if k.startswith("lstm.")}
+    x = rng.standard_normal((B, T, C)).astype(np.float32)
+    dy_all = (rng.standard_normal((B, T, H)) * 0.1).astype(np.float32)
+    dy_last = rng.standard_normal((B, H)).astype(np.float32)
+    y, saved = lstm.lstm_forward(x, lp, L, return_saved=True)
+    dy = dy_all.astype(np.float64).copy()
+    dy[:, -1] += dy_last
+    dx_ref, g_ref = lstm.lstm_backward(dy, lp, saved, L)
+    names = {}
+    ws = _run_lstm(p, x, dy_all, dy_last, C, H, L, torch.float32, cuda, info=names)
+    per_step = _run_lstm(p, x, dy_all, dy_last, C, H, L, torch.float32, cuda, {"CSN_NO_PERSIST": "1"})
+    _assert_same_bits(ws["y_all"], per_step["y_all"], "weight-stationary vs per-step float32 forward: y_all")
+    for k in ws:
+        assert _rel(ws[k], per_step[k]) < 2e-6, (k, _rel(ws[k], per_step[k]))
+    assert np.abs(ws["y_all"] - y).max() < 2e-5
+    assert _rel(ws["dx"], dx_ref) < 1e-5
+    for k, v in g_ref.items():
+        assert _rel(ws[k], v) < 1e-5, (k, _rel(ws[k], v))
+    # identical rows give identical bits whatever tile / row group they sit in (every row sees one summation order)
+    if B >= 130:
+        xx = x.copy()
+        xx[129] = xx[0]
+        xx[64] = xx[0]
+        dya, dyl = dy_all.copy(), dy_last.copy()
+        dya[129] = dya[64] = dya[0]
+        dyl[129] = dyl[64] = dyl[0]
+        rep = _run_lstm(p, xx, dya, dyl, C, H, L, torch.float32, cuda)
+        for r in (64, 129):
+            _assert_same_bits(rep["y_all"][r], rep["y_all"][0], f"row {r} vs row 0: y_all")
+            _assert_same_bits(rep["dx"][r], rep["dx"][0], f"row {r} vs row 0: dx")
+
+
+@pytest.mark.gpu
+def test_f32_weight_stationary_path_is_the_one_that_runs(cuda):
+    m = Model(input_size=16, lstm_size=128, lstm_layers=2, output_size=8, include_top=False, compute_dtype=torch.float32).to(cuda)
+    x = torch.randn(4, 12, 16, device=cuda)
+    m.lstm(x, want_all=True)
+    torch.cuda.synchronize()
+    plans = m.lstm.all_plans()
+    assert plans and all(pl.kernel_names() == ("lstm_fwd_f32_persist_kernel", "lstm_bwd_f32_persist_kernel") for pl in plans)

@@ -8,7 +8,7 @@ cd "$(dirname "$0")/../cerebralsignalnetworks_amd/csrc"
 make -j7 all > /dev/null
 B=../../build/csrc; A=../../build/abl_$name; mkdir -p $A
 objs=""
-for s in util eeg_filter gemm lstm_cell lstm_cell_blk lstm_fwd_persist lstm_fwd_ns lstm_bwd_persist lstm loss retrieval; do
+for s in util eeg_filter gemm lstm_cell lstm_cell_blk lstm_fwd_persist lstm_fwd_ns lstm_bwd_persist lstm_f32_persist lstm loss retrieval; do
   if [[ " $* " == *" $s.hip "* ]]; then
     /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -ffp-contract=on $flags -c $s.hip -o $A/$s.o &
     objs="$objs $A/$s.o"
