@@ -82,9 +82,13 @@ def rel(a, b):
     return float(np.linalg.norm(a - b) / max(1e-30, np.linalg.norm(b)))
 
 
-for (B, C, H, L, Tn) in ((256, 16, 1024, 2, T), (256, 128, 1024, 2, T), (256, 128, 768, 2, T), (1024, 128, 768, 2, 500)):
+# (float32 cases, round 4: the weight-stationary float32 kernels of lstm_f32_persist.hip -- fragment-major hand-off slots of
+#  up to 4.6 GB per layer at T = 1100, and 16 row tiles walked in blocks of 5 / 4 at B = 1024)
+for (B, C, H, L, Tn, cdt) in ((256, 16, 1024, 2, T, torch.bfloat16), (256, 128, 1024, 2, T, torch.bfloat16),
+                              (256, 128, 768, 2, T, torch.bfloat16), (1024, 128, 768, 2, 500, torch.bfloat16),
+                              (256, 128, 1024, 2, T, torch.float32), (1024, 128, 768, 2, 500, torch.float32)):
     torch.manual_seed(3)
-    m = HipLSTM(C, H, L, compute_dtype=torch.bfloat16).to(dev)
+    m = HipLSTM(C, H, L, compute_dtype=cdt).to(dev)
     x = torch.randn(B, Tn, C, device=dev, requires_grad=True)
     w = torch.randn(B, Tn, H, device=dev) / float(np.sqrt(Tn))
     y_all, _ = m(x, want_all=True)
@@ -104,8 +108,12 @@ for (B, C, H, L, Tn) in ((256, 16, 1024, 2, T), (256, 128, 1024, 2, T), (256, 12
     dx_t = np.array([rel(dx_got[:, t], dx_ref[:, t]) for t in range(Tn)])
     # bf16 operands (8 significant bits) through up to 1100 recurrent steps: the per-step outputs stay within a few 1e-3 of
     # the float64 oracle, the input gradient within a few 1e-2; a wrapped offset gives 1.0
-    ok = per_t.max() < 2e-2 and dx_t.max() < 6e-2 and rel(dx_got, dx_ref) < 3e-2 and (Tn <= 1024 or late < 2e-2)
+    # (float32: 1e-4 / 1e-3 -- the recurrence amplifies float32 rounding over a thousand steps, a wrapped offset gives 1.0)
+    f32 = cdt == torch.float32
+    ok = (per_t.max() < (1e-4 if f32 else 2e-2) and dx_t.max() < (1e-3 if f32 else 6e-2) and rel(dx_got, dx_ref) < (1e-4 if f32 else 3e-2)
+          and (Tn <= 1024 or late < (1e-4 if f32 else 2e-2)))
     bad += 0 if ok else 1
+    path = ("f32 " if f32 else "") + str(path) + (" " + "/".join(m.all_plans()[0].kernel_names()) if f32 else "")
     print(f"{'ok  ' if ok else 'FAIL'} oracle rows {rows} B{B} T{Tn} C{C} H{H} L{L} (path {path}): y worst step {int(per_t.argmax())} "
           f"rel {per_t.max():.2e}, steps >= 1024: {late:.2e}; dx worst step {int(dx_t.argmax())} rel {dx_t.max():.2e}, whole {rel(dx_got, dx_ref):.2e}",
           flush=True)
