@@ -29,7 +29,8 @@ HBM_PEAK_GBS = 8000.0            # HBM3E spec, same guide
 # committed rocprofv3 --pmc passes per workload (tools/pmc_traffic.sh: FETCH_SIZE / WRITE_SIZE; tools/pmc_counters.sh:
 # MFMA-busy / wait / L2-hit / LDS-conflict), each carrying the kernel-source fingerprint it was collected with
 PMC_FILES = {"cfg2": ("r04_pmc_traffic.json", "r04_pmc_counters.json"),
-             "cfg4": ("r04_cfg4_pmc_traffic.json", "r04_cfg4_pmc_counters.json")}
+             "cfg4": ("r04_cfg4_pmc_traffic.json", "r04_cfg4_pmc_counters.json"),
+             "cfg2/f32": ("r04_f32_pmc_traffic.json", "r04_f32_pmc_counters.json")}      # (--dtype f32: the exact-float32 path)
 
 
 def csrc_sha16():
@@ -411,8 +412,10 @@ def main():
             traffic_source = None
             try:
                 wl = {(256, 128, 500, 768, 2): "cfg2", (256, 128, 440, 1024, 2): "cfg4"}.get((B, C, T, H, L))
+                if wl is not None and args.dtype != "bf16":
+                    wl = wl + "/f32" if wl + "/f32" in PMC_FILES else None
                 if wl is None:
-                    raise KeyError("PMC passes are committed for the cfg2 and cfg4 workloads only")
+                    raise KeyError("PMC passes are committed for the cfg2 and cfg4 workloads (bf16) and cfg2 (float32) only")
                 PMC_TRAFFIC_FILE, PMC_COUNTERS_FILE = PMC_FILES[wl]
                 pmc = json.load(open(os.path.join(ROOT, "profiles", PMC_TRAFFIC_FILE)))
                 cnt = json.load(open(os.path.join(ROOT, "profiles", PMC_COUNTERS_FILE)))

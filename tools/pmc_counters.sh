@@ -29,7 +29,7 @@ for g in "${groups[@]}"; do
 done
 python3 - "$out" "$*" <<'PY'
 import csv, glob, json, sys, collections
-names = ["lstm_bwd_persist_kernel", "lstm_fwd_persist_kernel", "lstm_fwd_ns_kernel", "gemm_nt_wide_kernel", "gemm_nt_256_kernel", "gemm_nt_dma_kernel", "gemm_tn_256_kernel",
+names = ["lstm_bwd_persist_kernel", "lstm_fwd_persist_kernel", "lstm_fwd_ns_kernel", "lstm_fwd_f32_persist_kernel", "lstm_bwd_f32_persist_kernel", "gemm_generic_kernel", "gemm_f32_128_kernel", "gemm_nt_wide_kernel", "gemm_nt_256_kernel", "gemm_nt_dma_kernel", "gemm_tn_256_kernel",
          "gemm_tn_bf16_kernel", "gemm_tn_n128_kernel", "eeg_filter_scan_kernel", "lstm_cell_fwd_il_kernel", "lstm_cell_bwd_il_kernel",
          "rmsprop_flat_kernel"]
 res = {"bench_args": sys.argv[2], "command": "rocprofv3 --pmc <group> --kernel-trace -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-retrieval --no-f32-line --no-parity (one pass per group)",

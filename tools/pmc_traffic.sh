@@ -14,7 +14,7 @@ import csv, glob, json, sys, collections
 res = {"bench_args": sys.argv[2], "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE (separate passes) --kernel-trace -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-retrieval --no-f32-line --no-parity",
        "units": "counter values are KiB per dispatch; corrected = (2*FETCH_SIZE + WRITE_SIZE)*1024 bytes (gfx950: FETCH_SIZE counts 128-B requests as 64 B)",
        "kernels": {}}
-names = ["lstm_bwd_persist_kernel", "lstm_fwd_persist_kernel", "lstm_fwd_ns_kernel", "gemm_nt_wide_kernel", "gemm_nt_256_kernel", "gemm_nt_dma_kernel", "gemm_nt_bf16_kernel",
+names = ["lstm_bwd_persist_kernel", "lstm_fwd_persist_kernel", "lstm_fwd_ns_kernel", "lstm_fwd_f32_persist_kernel", "lstm_bwd_f32_persist_kernel", "gemm_generic_kernel", "gemm_f32_128_kernel", "gemm_nt_wide_kernel", "gemm_nt_256_kernel", "gemm_nt_dma_kernel", "gemm_nt_bf16_kernel",
          "gemm_tn_256_kernel", "gemm_tn_bf16_kernel", "eeg_filter_scan_kernel", "colsum_partial_kernel", "lstm_cell_bwd_il_kernel"]
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     f = glob.glob(f"gpurun_out/pmcb_{c}/**/*counter_collection.csv", recursive=True)[0]
