@@ -258,7 +258,8 @@ class LstmPlan:
         return (d.B, d.T, d.I, d.H, d.L, d.dtype, self.training)
 
     def path(self):
-        """0 generic cells, 1 per-diagonal bf16 launches, 2 weight-stationary forward, 3 + weight-stationary backward."""
+        """0 generic cells, 1 per-diagonal bf16 launches, 2 weight-stationary forward, 3 + weight-stationary backward, 4 the
+        exact-float32 path's weight-stationary recurrence."""
         return load().csn_lstm_plan_path(self._plan)
 
     def kernel_names(self):

@@ -362,7 +362,7 @@ extern "C" size_t csn_lstm_plan_workspace_bytes(const csnLstmPlan* P) { return P
 
 extern "C" int csn_lstm_plan_path(const csnLstmPlan* P) {
   if (P == nullptr) return -1;
-  return P->w.persist_bwd ? 3 : (P->w.persist ? 2 : (P->w.il ? 1 : 0));
+  return P->w.f32_persist ? 4 : (P->w.persist_bwd ? 3 : (P->w.persist ? 2 : (P->w.il ? 1 : 0)));
 }
 
 extern "C" int csn_lstm_plan_dgates_copies(const csnLstmPlan* P) { return P == nullptr ? -1 : P->dgates_copies; }

@@ -100,7 +100,9 @@ void csn_lstm_plan_destroy(csnLstmPlan* plan);
  * caller owns it; one plan may be used with several workspaces (e.g. several forwards awaiting their backward). */
 size_t csn_lstm_plan_workspace_bytes(const csnLstmPlan* plan);
 /* Which kernels the plan runs: 0 generic per-step cells (exact f32 / odd shapes), 1 per-diagonal bf16 launches,
- * 2 weight-stationary forward, 3 weight-stationary forward and backward. */
+ * 2 weight-stationary forward, 3 weight-stationary forward and backward (bf16), 4 weight-stationary forward and
+ * backward of the exact-float32 path (CSN_F32, H in {128, 256, 384, 512, 768, 1024}, a whole MI355X: one launch per layer and
+ * block of batch rows; its workspace also holds fragment-major copies of h and of the gate gradients). */
 int csn_lstm_plan_path(const csnLstmPlan* plan);
 /* Copies of the gate gradients the plan's LAST csn_lstm_backward wrote per step: 2 = the fragment-major hand-off slab
  * and a row-major copy for the GEMMs behind the recurrence (always, in this library); 1 = the hand-off slabs alone,

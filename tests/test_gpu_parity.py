@@ -1155,4 +1155,13 @@ def test_f32_weight_stationary_path_is_the_one_that_runs(cuda):
     m.lstm(x, want_all=True)
     torch.cuda.synchronize()
     plans = m.lstm.all_plans()
-    assert plans and all(pl.kernel_names() == ("lstm_fwd_f32_persist_kernel", "lstm_bwd_f32_persist_kernel") for pl in plans)
+    assert plans and all(pl.kernel_names() == ("lstm_fwd_f32_persist_kernel", "lstm_bwd_f32_persist_kernel") and pl.path() == 4
+                         for pl in plans)
+    os.environ["CSN_NO_PERSIST"] = "1"
+    try:
+        m2 = Model(input_size=16, lstm_size=128, lstm_layers=2, output_size=8, include_top=False, compute_dtype=torch.float32).to(cuda)
+        m2.lstm(x, want_all=True)
+        torch.cuda.synchronize()
+        assert all(pl.path() == 0 and pl.kernel_names()[0] == "lstm_cell_fwd_ks_kernel" for pl in m2.lstm.all_plans())
+    finally:
+        del os.environ["CSN_NO_PERSIST"]
