@@ -1157,6 +1157,14 @@ def test_f32_weight_stationary_path_is_the_one_that_runs(cuda):
     plans = m.lstm.all_plans()
     assert plans and all(pl.kernel_names() == ("lstm_fwd_f32_persist_kernel", "lstm_bwd_f32_persist_kernel") and pl.path() == 4
                          for pl in plans)
+    # inference plans (no saved gates, no gradient slots) give the bits of the training plan's forward
+    y_train, _ = m.lstm(x, want_all=True)
+    m.eval()
+    with torch.no_grad():
+        y_eval, _ = m.lstm(x, want_all=True)
+    torch.cuda.synchronize()
+    assert any(not pl.training for pl in m.lstm.all_plans()) and all(pl.status() == 0 for pl in m.lstm.all_plans())
+    _assert_same_bits(y_eval.cpu().numpy(), y_train.detach().cpu().numpy(), "inference plan vs training plan: y_all")
     os.environ["CSN_NO_PERSIST"] = "1"
     try:
         m2 = Model(input_size=16, lstm_size=128, lstm_layers=2, output_size=8, include_top=False, compute_dtype=torch.float32).to(cuda)
