@@ -10,7 +10,9 @@ from cerebralsignalnetworks_amd.lstm_model import HipLSTM
 dev = torch.device("cuda:0")
 B, T, C, H, L = 256, 500, 128, 768, 2
 torch.manual_seed(1)
-m = HipLSTM(C, H, L, compute_dtype=torch.bfloat16).to(dev)
+# (second argument "f32": the exact-float32 path's weight-stationary kernels, lstm_f32_persist.hip)
+cdt = torch.float32 if len(sys.argv) > 2 and sys.argv[2] == "f32" else torch.bfloat16
+m = HipLSTM(C, H, L, compute_dtype=cdt).to(dev)
 x = torch.randn(B, T, C, device=dev)
 dy = torch.randn(B, H, device=dev)
 
@@ -33,7 +35,7 @@ reps = int(sys.argv[1]) if len(sys.argv) > 1 else 12
 for rep in range(reps):
     stop = torch.zeros(1)
     with torch.cuda.stream(side):
-        for k in range(60 + 20 * (rep % 3)):              # ~ the duration of one forward + backward
+        for k in range((60 + 20 * (rep % 3)) * (5 if cdt == torch.float32 else 1)):              # ~ the duration of one forward + backward
             big[(k + 1) % 3].copy_(big[k % 3])
             if k % 7 == rep % 7:
                 big[2].mul_(1.0001)
@@ -45,5 +47,5 @@ for rep in range(reps):
         print("rep", rep, "MISMATCH", diff, flush=True)
     else:
         print("rep", rep, "identical", flush=True)
-print("stress summary: %d of %d repetitions differ" % (bad, reps))
+print("stress summary (%s, kernels %s): %d of %d repetitions differ" % (str(cdt).split(".")[-1], "/".join(m.all_plans()[0].kernel_names()), bad, reps))
 sys.exit(1 if bad else 0)

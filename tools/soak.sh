@@ -7,6 +7,8 @@ mkdir -p $(dirname $out)
 date
 echo "handoff_stress 300 reps (cfg2 forward+backward under a noisy second stream; every output bit-equal to the quiet run)"
 python3 tools/handoff_stress.py 300 2>&1 | tail -4
+echo "handoff_stress 100 reps, exact-float32 path (weight-stationary float32 kernels)"
+python3 tools/handoff_stress.py 100 f32 2>&1 | tail -2
 echo "tags_check 40 reps per form (debug library: stale-slot detector)"
 CSN_LIB_PATH=$PWD/cerebralsignalnetworks_amd/lib/libcsn_hip_tags.so python3 tools/tags_check.py 40 2>&1 | tail -1
 echo "bench.py --steps 2000 (cfg2; status word checked after the timed region)"
