@@ -1173,3 +1173,16 @@ def test_f32_weight_stationary_path_is_the_one_that_runs(cuda):
         assert all(pl.path() == 0 and pl.kernel_names()[0] == "lstm_cell_fwd_ks_kernel" for pl in m2.lstm.all_plans())
     finally:
         del os.environ["CSN_NO_PERSIST"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt", ["bf16", "f32"])
+def test_two_weight_stationary_plans_on_two_streams(cuda, dt):
+    """tests/diag/two_streams.py: two models of the benchmark width, forward + backward enqueued on two streams so that their
+    weight-stationary launches (every workgroup of a launch co-resident, one per CU) can meet on the device: no bounded wait
+    times out and the gradients are the bits of the serial runs."""
+    import subprocess
+    import sys
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "diag", "two_streams.py"), "4", dt],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
