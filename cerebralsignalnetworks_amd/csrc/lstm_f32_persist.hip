@@ -17,7 +17,9 @@
 // read), stored write-through (sc1) and read with sc1 loads (this CU's L1 bypassed); a producer drains its stores
 // (s_waitcnt vmcnt(0)), the workgroup meets at a barrier, one lane raises the producer's word of the step's flag line
 // (relaxed, agent scope); a consumer wave polls exactly the words of the producers whose units / gate block it
-// contracts.  The placement-independent flag protocol of lstm_fwd_persist.hip, nothing else: at 10 us of MFMA issue per
+// contracts.  ONLY the payload is stored in front of the drain: the saved tensors / row-major results (gates, c, h, dgates:
+// streaming stores to cold HBM lines, acknowledged microseconds later) follow the flag, and the next step's inputs are
+// requested there too -- with them in front of the drain a forward step took 19.9 instead of 16 us.  The placement-independent flag protocol of lstm_fwd_persist.hip, nothing else: at 10 us of MFMA issue per
 // step the 2 - 3 us of hand-off are not where the time is.  Every spin is bounded (status word 0 on time-out).
 // All workgroups of a launch must be co-resident: the grid is at most 256 (one workgroup per CU: > 256 registers per
 // lane), larger batches walk their M-tiles in blocks (rows are independent).
@@ -47,7 +49,7 @@ typedef __attribute__((ext_vector_type(4))) unsigned fu32x4;
 static constexpr unsigned long long kF32SpinTimeoutTicks = 20000000ull;   // 0.2 s of the 100 MHz wall clock
 
 #ifndef CSN_F32_ABL
-#define CSN_F32_ABL 0      // timing-only ablations (tools/abl_build.sh): 1 no MFMAs, 2 no operand loads, 4 cheap gate math, 8 no polls, 16 no drain
+#define CSN_F32_ABL 0      // timing-only ablations (tools/abl_build.sh): 1 no MFMAs, 2 no operand loads, 4 cheap gate math, 8 no polls, 16 no drain, 32 saved-tensor stores in front of the drain
 #endif
 __device__ __forceinline__ f32x4 f32p_load_sc1(__amdgpu_buffer_rsrc_t rsrc, int byte_off) {
 #if CSN_F32_ABL & 2
@@ -64,6 +66,15 @@ __device__ __forceinline__ f32x4 f32p_mfma(float a, float b, const f32x4& c) {
   return (f32x4){c[0] + a * b, c[1], c[2], c[3]};
 #endif
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// saved tensors / row-major results: streaming (non-temporal) stores; bit 64 of CSN_F32_ABL: plain stores (timing comparison)
+__device__ __forceinline__ void f32p_cold_store(f32x4* p, const f32x4& v) {
+#if CSN_F32_ABL & 64
+  *p = v;
+#else
+  nt_store(p, v);
+#endif
 }
 
 // wait until every polled word is raised (lane i < n watches word i of `line`); bounded
@@ -91,7 +102,7 @@ __global__ void __launch_bounds__(256) lstm_fwd_f32_persist_kernel(F32PersistFwd
   constexpr int H = 64 * KS, G = 4 * H;
   constexpr int NSL = H / 16;              // producer slices of a tile
   constexpr int NPW = NSL / 4;             // ... whose units fall into one wave's K quarter
-  constexpr int RING = KS < 4 ? KS : 4;    // 16-wide k-steps of h in flight per wave
+  constexpr int RING = KS < 4 ? KS : 4;    // 16-wide k-steps of h in flight per wave (3 and 6: no faster)
   // partial tiles on their way to the wave that finishes them: [dst row group][src wave, without dst][gate][lane]
   __shared__ f32x4 part[4][3][4][64];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -227,17 +238,22 @@ __global__ void __launch_bounds__(256) lstm_fwd_f32_persist_kernel(F32PersistFwd
 #endif
       cp[r] = cn[r];
     }
-    if (row_ok) {
-      if (a.gates != nullptr) {
-        f32x4* gp = reinterpret_cast<f32x4*>(a.gates + ((int64_t)t * B + mrow) * G + ub);
-        nt_store(gp, (f32x4){gi[0], gi[1], gi[2], gi[3]});
-        nt_store(gp + H / 4, (f32x4){gf[0], gf[1], gf[2], gf[3]});
-        nt_store(gp + 2 * (H / 4), (f32x4){gg[0], gg[1], gg[2], gg[3]});
-        nt_store(gp + 3 * (H / 4), (f32x4){go[0], go[1], go[2], go[3]});
+    auto cold_stores = [&]() {
+      if (row_ok) {
+        if (a.gates != nullptr) {
+          f32x4* gp = reinterpret_cast<f32x4*>(a.gates + ((int64_t)t * B + mrow) * G + ub);
+          f32p_cold_store(gp, (f32x4){gi[0], gi[1], gi[2], gi[3]});
+          f32p_cold_store(gp + H / 4, (f32x4){gf[0], gf[1], gf[2], gf[3]});
+          f32p_cold_store(gp + 2 * (H / 4), (f32x4){gg[0], gg[1], gg[2], gg[3]});
+          f32p_cold_store(gp + 3 * (H / 4), (f32x4){go[0], go[1], go[2], go[3]});
+        }
+        f32p_cold_store(reinterpret_cast<f32x4*>(a.c_all + ((int64_t)(t + 1) * B + mrow) * H + ub), (f32x4){cn[0], cn[1], cn[2], cn[3]});
+        f32p_cold_store(reinterpret_cast<f32x4*>(a.h_all + ((int64_t)(t + 1) * B + mrow) * H + ub), (f32x4){hn[0], hn[1], hn[2], hn[3]});
       }
-      nt_store(reinterpret_cast<f32x4*>(a.c_all + ((int64_t)(t + 1) * B + mrow) * H + ub), (f32x4){cn[0], cn[1], cn[2], cn[3]});
-      nt_store(reinterpret_cast<f32x4*>(a.h_all + ((int64_t)(t + 1) * B + mrow) * H + ub), (f32x4){hn[0], hn[1], hn[2], hn[3]});
-    }
+    };
+#if CSN_F32_ABL & 32
+    cold_stores();      // (timing comparison: round 4's first form, every store in front of the drain)
+#endif
     {
       // the hand-off payload: this wave's finished 16 x 16 tile as ONE fragment block, written through (rows beyond B:
       // whatever the clamped inputs gave -- finite, read only into their own, never stored, columns)
@@ -253,6 +269,9 @@ __global__ void __launch_bounds__(256) lstm_fwd_f32_persist_kernel(F32PersistFwd
     CSN_F32STAMP(4);
     __syncthreads();
     if (tid == 0) __hip_atomic_store(flags + (size_t)(t + 1) * flag_step + slice, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#if !(CSN_F32_ABL & 32)
+    cold_stores();
+#endif
     CSN_F32STAMP(5);
   }
 }
@@ -265,7 +284,7 @@ __global__ void __launch_bounds__(256) lstm_bwd_f32_persist_kernel(F32PersistBwd
   constexpr int H = 64 * KS, G = 4 * H;
   constexpr int NSL = H / 16;
   constexpr int KSB = H / 16;              // 16-wide k-steps of one gate block
-  constexpr int RING = KS >= 16 ? 6 : (KSB < 8 ? KSB : 8);      // k-steps of dgates in flight per wave (16 MFMAs = 0.2 us each)
+  constexpr int RING = KS >= 16 ? 6 : (KSB < 4 ? KSB : 4);      // k-steps of dgates in flight per wave (measured at H = 768: 2 - 4 equal, 6 / 8 / 12 / 16 slower by 1 / 2 / 5 / 27 %: registers, not latency)
   __shared__ f32x4 part[4][3][64];         // [dst row group][src wave, without dst][lane]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -291,6 +310,20 @@ __global__ void __launch_bounds__(256) lstm_bwd_f32_persist_kernel(F32PersistBwd
   unsigned* const flags = a.flags + (size_t)(a.mt0 + mt) * kF32FlagLine;
   const int bslot_bytes = a.MT_total * 64 * G * 4;
 
+  // saved tensors of a step + its incoming gradient: always the same unconditional loads, requested one step EARLY (right
+  // behind the publish of the step before): they come from HBM, and queued behind the first operand groups of their own
+  // step -- vector-memory operations return in order -- they held the later groups back (the ring's 8 groups cover 1.7 us)
+  f32x4 sg[4], scc, scp, sdy;
+  auto request_saved = [&](int tt) {
+    const f32x4* gp = reinterpret_cast<const f32x4*>(a.gates + ((int64_t)tt * B + mr) * G + ub);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) sg[g] = nt_load(gp + g * (H / 4));
+    scc = nt_load(reinterpret_cast<const f32x4*>(a.c_all + ((int64_t)(tt + 1) * B + mr) * H + ub));
+    scp = nt_load(reinterpret_cast<const f32x4*>(a.c_all + ((int64_t)tt * B + mr) * H + ub));
+    const float* dsrc = a.dy != nullptr ? a.dy + (int64_t)tt * B * H : ((a.dy_last != nullptr && tt == T - 1) ? a.dy_last : a.zeros);
+    sdy = nt_load(reinterpret_cast<const f32x4*>(dsrc + (int64_t)mr * H + ub));
+  };
+  request_saved(T - 1);
 #ifdef CSN_PSTAMPS
   unsigned long long last_ = wall_clock64();
 #endif
@@ -298,17 +331,6 @@ __global__ void __launch_bounds__(256) lstm_bwd_f32_persist_kernel(F32PersistBwd
     f32x4 acc[4];
 #pragma unroll
     for (int rg = 0; rg < 4; ++rg) acc[rg] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    // saved tensors of this step + the incoming gradient: always the same unconditional loads
-    f32x4 sg[4], scc, scp, sdy;
-    auto request_saved = [&]() {
-      const f32x4* gp = reinterpret_cast<const f32x4*>(a.gates + ((int64_t)t * B + mr) * G + ub);
-#pragma unroll
-      for (int g = 0; g < 4; ++g) sg[g] = nt_load(gp + g * (H / 4));
-      scc = nt_load(reinterpret_cast<const f32x4*>(a.c_all + ((int64_t)(t + 1) * B + mr) * H + ub));
-      scp = nt_load(reinterpret_cast<const f32x4*>(a.c_all + ((int64_t)t * B + mr) * H + ub));
-      const float* dsrc = a.dy != nullptr ? a.dy + (int64_t)t * B * H : ((a.dy_last != nullptr && t == T - 1) ? a.dy_last : a.zeros);
-      sdy = nt_load(reinterpret_cast<const f32x4*>(dsrc + (int64_t)mr * H + ub));
-    };
     if (t < T - 1) {
       // dgates_{t+1}: every slice of the tile produced a part of this wave's gate block
       f32p_wait_flags(flags + (size_t)(t + 1) * flag_step, NSL, lane, a.error_flag);
@@ -325,8 +347,6 @@ __global__ void __launch_bounds__(256) lstm_bwd_f32_persist_kernel(F32PersistBwd
         issue(i);
         __builtin_amdgcn_sched_barrier(0);
       }
-      request_saved();
-      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int i = 0; i < KSB; ++i) {
 #pragma unroll
@@ -339,8 +359,6 @@ __global__ void __launch_bounds__(256) lstm_bwd_f32_persist_kernel(F32PersistBwd
           __builtin_amdgcn_sched_barrier(0);
         }
       }
-    } else {
-      request_saved();
     }
     CSN_F32STAMP(9);
 
@@ -385,13 +403,18 @@ __global__ void __launch_bounds__(256) lstm_bwd_f32_persist_kernel(F32PersistBwd
       f32p_store_wt(ddst, o + 2 * KSB * 1024, (f32x4){dag[0], dag[1], dag[2], dag[3]});
       f32p_store_wt(ddst, o + 3 * KSB * 1024, (f32x4){dao[0], dao[1], dao[2], dao[3]});
     }
+    auto cold_stores = [&]() {
     if (row_ok) {      // the row-major result the GEMMs behind the recurrence read
       f32x4* op = reinterpret_cast<f32x4*>(a.dgates + ((int64_t)t * B + mrow) * G + ub);
-      nt_store(op, (f32x4){dai[0], dai[1], dai[2], dai[3]});
-      nt_store(op + H / 4, (f32x4){daf[0], daf[1], daf[2], daf[3]});
-      nt_store(op + 2 * (H / 4), (f32x4){dag[0], dag[1], dag[2], dag[3]});
-      nt_store(op + 3 * (H / 4), (f32x4){dao[0], dao[1], dao[2], dao[3]});
+      f32p_cold_store(op, (f32x4){dai[0], dai[1], dai[2], dai[3]});
+      f32p_cold_store(op + H / 4, (f32x4){daf[0], daf[1], daf[2], daf[3]});
+      f32p_cold_store(op + 2 * (H / 4), (f32x4){dag[0], dag[1], dag[2], dag[3]});
+      f32p_cold_store(op + 3 * (H / 4), (f32x4){dao[0], dao[1], dao[2], dao[3]});
     }
+    };
+#if CSN_F32_ABL & 32
+    cold_stores();      // (timing comparison: round 4's first form, every store in front of the drain)
+#endif
     CSN_F32STAMP(11);
 #if !(CSN_F32_ABL & 16)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -399,6 +422,10 @@ __global__ void __launch_bounds__(256) lstm_bwd_f32_persist_kernel(F32PersistBwd
     CSN_F32STAMP(12);
     __syncthreads();
     if (tid == 0) __hip_atomic_store(flags + (size_t)t * flag_step + slice, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (t > 0) request_saved(t - 1);      // (in front of the cold stores: the other order is 0.15 ms per launch slower)
+#if !(CSN_F32_ABL & 32)
+    cold_stores();
+#endif
     CSN_F32STAMP(13);
   }
 }
