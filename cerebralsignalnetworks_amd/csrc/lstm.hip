@@ -44,7 +44,7 @@ struct LayerWs {
 };
 struct WsLayout {
   LayerWs layer[8];
-  size_t x_c, x_blk, wih0_blk, dy_tm, tn_scratch, colsum, tn_scratch2, colsum2, status, agree, agree_b, tile_ctr, zeros_bh, total;
+  size_t x_c, x_blk, wih0_blk, dy_tm, tn_scratch, colsum, tn_scratch2, colsum2, status, agree, agree_b, tile_ctr, zeros_bh, f32_bias_part, total;
   // weight-stationary paths: everything that must be zero at the start of a forward / a backward sits in ONE block each
   size_t zero_fwd, zero_fwd_bytes, zero_bwd, zero_bwd_bytes;
   bool fuse_x;
@@ -136,6 +136,7 @@ static WsLayout make_layout(const csnLstmDesc& d, int training, const Options& o
     if (training) {
       for (int l = 0; l < d.L; ++l) w.layer[l].dg_blk_all = take((size_t)d.T * Bpad * G * 4);
       w.zeros_bh = take((size_t)d.B * H * 4);
+      w.f32_bias_part = take(MTt * 4 * G * 4);      // per-row-group bias-gradient partial sums of ONE layer (consumed before the next launch)
       w.zero_bwd = off;
       for (int l = 0; l < d.L; ++l) w.layer[l].bflags = take((size_t)d.T * MTt * kF32FlagLine * 4);
       w.zero_bwd_bytes = off - w.zero_bwd;
@@ -215,6 +216,16 @@ __global__ void tb_to_bt_kernel(const float* __restrict__ src, float* __restrict
 __global__ void add_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, int64_t n) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] += src[i];
+}
+
+// out[n] = part[0][n] + part[1][n] + ... (fixed order): the row groups' bias-gradient partial sums of the float32 backward
+__global__ void sum_rows_kernel(const float* __restrict__ part, int P, int64_t n, float* __restrict__ out, float* __restrict__ out2) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.f;
+  for (int p = 0; p < P; ++p) s += part[(int64_t)p * n + i];
+  out[i] = s;
+  out2[i] = s;
 }
 
 static inline unsigned grid_for(int64_t n) {
@@ -720,6 +731,7 @@ static int backward_f32p(Plan& P, char* ws, const float* dy_last, const float* d
     a.zeros = (const float*)(ws + w.zeros_bh);
     a.dgates = (float*)(ws + L.dgates);
     a.dg_blk = (float*)(ws + L.dg_blk_all);
+    a.bias_part = (float*)(ws + w.f32_bias_part);
     a.flags = (unsigned*)(ws + L.bflags);
     a.error_flag = (unsigned*)(ws + w.status);
     a.B = B; a.T = T; a.MT_total = MTt;
@@ -731,6 +743,9 @@ static int backward_f32p(Plan& P, char* ws, const float* dy_last, const float* d
       if ((rc = prof_pair(g_prof, 1, true, st))) return rc;
       ++n_launch;
     }
+    // bias gradients: the row groups' partial sums in fixed order (db_ih = db_hh)
+    sum_rows_kernel<<<(unsigned)((G + 255) / 256), 256, 0, st>>>((const float*)(ws + w.f32_bias_part), MTt * 4, G, db_ih[l], db_hh[l]);
+    CSN_LAUNCH_CHECK();
     // gradient w.r.t. this layer's input = dy of the layer below, whole sequence
     if (l > 0 && (rc = gemm_nt(ws + L.dgates, ws + L.wiht, nullptr, ws + L.dx, TB, H, G, CSN_F32, CSN_F32, 0, st, P.opt))) return rc;
   }
@@ -744,8 +759,6 @@ static int backward_f32p(Plan& P, char* ws, const float* dy_last, const float* d
     const void* inp = l == 0 ? (const void*)(ws + w.x_c) : (const void*)(ws + w.layer[l - 1].h_all + (size_t)B * H * 4);
     if ((rc = gemm_tn_full(ws + L.dgates, ws + L.h_all, dw_hh[l], G, H, TB, CSN_F32, ws + w.tn_scratch, st, P.opt))) return rc;
     if ((rc = gemm_tn_full(ws + L.dgates, inp, dw_ih[l], G, I, TB, CSN_F32, ws + w.tn_scratch, st, P.opt))) return rc;
-    if ((rc = launch_colsum(ws + L.dgates, TB, G, CSN_F32, db_ih[l], ws + w.colsum, st))) return rc;
-    CSN_HIP_CHECK(hipMemcpyAsync(db_hh[l], db_ih[l], (size_t)G * 4, hipMemcpyDeviceToDevice, st));
     P.grads_ready(l);
   }
   if (dx) {

@@ -30,6 +30,7 @@ struct F32PersistBwdArgs {
   const float* zeros;      // [B][H] zeros (steps without an incoming gradient still take ONE unconditional load)
   float* dgates;           // [T][B][4H] pre-activation gradients (row-major: what the GEMMs read)
   float* dg_blk;           // [T][MT_total * 4 row groups][4H / 16][64 lanes][4]: fragment-major copy, the hand-off payload
+  float* bias_part;        // [MT_total * 4 row groups][4H]: column sums of dgates over this launch's steps, per 16-row group (or null)
   unsigned* flags;         // [T][MT_total][kF32FlagLine], zeroed per backward
   unsigned* error_flag;
   int B, T;

@@ -1129,7 +1129,9 @@ def test_f32_weight_stationary_recurrence(cuda, B, T, C, H, L):
     per_step = _run_lstm(p, x, dy_all, dy_last, C, H, L, torch.float32, cuda, {"CSN_NO_PERSIST": "1"})
     _assert_same_bits(ws["y_all"], per_step["y_all"], "weight-stationary vs per-step float32 forward: y_all")
     for k in ws:
-        assert _rel(ws[k], per_step[k]) < 2e-6, (k, _rel(ws[k], per_step[k]))
+        # (bias gradients: the weight-stationary backward sums dgates over the steps as it produces them -- per lane over t, then
+        #  over the 16 rows of a row group, then the row groups in fixed order -- where the per-step path runs a column-sum pass)
+        assert _rel(ws[k], per_step[k]) < (1e-5 if "bias" in k else 2e-6), (k, _rel(ws[k], per_step[k]))
     assert np.abs(ws["y_all"] - y).max() < 2e-5
     assert _rel(ws["dx"], dx_ref) < 1e-5
     for k, v in g_ref.items():
